@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: rod-states/s of the fp64 D_N.X apply.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W  (N > 1, one rank per GPU, RCCL)
+
+A "step" is one pass of the hot path over one batch of synthetic state panels already resident in
+HBM: Y = D_N . X with N = 256 nodes and 65 536 rods (x 4 state columns) PER GPU — BASELINE.json
+configs[2] at N=1, configs[3] at 8 GPUs (weak scaling on the batch axis).  For N > 1 every step
+also all-gathers the integrated tip state of every rod over RCCL/xGMI, overlapped with the next
+step's apply on a side stream (north_star: "all-gather ... only to reassemble the final integrated
+state"); the apply itself needs no collective.
+
+Rank 0 prints ONE JSON line.  `roofline` is computed from ALGORITHMIC flops (8 N^2 per rod-state,
+SURVEY.md §8d) and the kernel's mean launch duration measured here with HIP events on the launch
+stream; `cpu_baseline` times the CPU oracle (test infrastructure, the checker only) on a bounded
+sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet dense fp64 matrix peak; 77.5 measured (profiles/r01_mfma_f64_probe.log)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256, help="Chebyshev nodes N")
+    ap.add_argument("--rods", type=int, default=65536, help="rods per GPU (4 state columns each)")
+    ap.add_argument("--operator", choices=["dn", "dnn_inv"], default="dn")
+    ap.add_argument("--gather", choices=["tip", "full", "none"], default="tip", help="exchange step when N > 1")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, budget_s: float):
+    """Oracle (kind "port") on a bounded sample, single thread like the reference's main.cpp."""
+    import oracle
+
+    A = oracle.dn(n)
+    rng = np.random.default_rng(0x5EED)
+    probe_rods = 64
+    X = np.asfortranarray(rng.uniform(-1, 1, size=(probe_rods * 4, n)).T)
+    oracle.apply(A, X)                                    # warm
+    t0 = time.perf_counter(); oracle.apply(A, X); t = time.perf_counter() - t0
+    rate = probe_rods / max(t, 1e-9)
+    rods = int(min(max(rate * budget_s * 0.45, probe_rods), 32768))
+    X = np.asfortranarray(rng.uniform(-1, 1, size=(rods * 4, n)).T)
+    best = float("inf")
+    reps = 2
+    for _ in range(reps):
+        t0 = time.perf_counter(); oracle.apply(A, X); best = min(best, time.perf_counter() - t0)
+    threads = oracle.max_threads()
+    t0 = time.perf_counter(); oracle.apply(A, X, threads=0); t_mt = time.perf_counter() - t0
+    return {
+        "value": rods / best, "unit": "rod-states/s", "cores": 1, "kind": "port",
+        "sample": f"oracle/sri_oracle.c single thread, {rods} rods x 4 cols at N={n}, best of {reps}",
+        "all_cores_value": rods / t_mt, "all_cores": threads,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
+    from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel
+
+    if not os.path.exists(sri.library_path()):
+        raise SystemExit("libsri_hip.so missing: run __graft_entry__.build() first (no CPU fallback)")
+
+    n, rods = args.n, args.rods
+    which = sri.OP_DN if args.operator == "dn" else sri.OP_DNN_INV
+    op = sri.SpectralApply(n, which, device=local_rank)
+    rows, M = op.rows, 4 * rods
+
+    g = torch.Generator(device=dev).manual_seed(0x5EED + rank)
+    X = torch.rand((M, rows), dtype=torch.float64, device=dev, generator=g) * 2 - 1   # synthetic U[-1,1) panel
+    Y = torch.empty_like(X)
+
+    # exchange step (N > 1): tips of step i gathered on a side stream under the apply of step i+1
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    tips_local = [torch.empty(M, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    tips_all = [torch.empty(M * world, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    full_all = torch.empty((M * world, rows), dtype=torch.float64, device=dev) if (world > 1 and args.gather == "full") else None
+    ready = [torch.cuda.Event() for _ in range(2)]
+    gathered = [torch.cuda.Event() for _ in range(2)]
+
+    def step(i: int, ev_pair=None):
+        if ev_pair is not None:
+            ev_pair[0].record()
+        op.apply(X, out=Y)
+        if ev_pair is not None:
+            ev_pair[1].record()
+        if world > 1 and args.gather != "none":
+            b = i & 1
+            if args.gather == "tip":
+                torch.cuda.current_stream().wait_event(gathered[b])   # buffer b free again
+                tips_local[b].copy_(Y[:, 0])
+                ready[b].record()
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ready[b])
+                    dist.all_gather_into_tensor(tips_all[b], tips_local[b])
+                    gathered[b].record()
+            else:
+                dist.all_gather_into_tensor(full_all, Y)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    # optional: one full-panel all-gather timed on its own (reported, never part of `value`)
+    full_gather_ms = None
+    if world > 1 and args.gather == "tip":
+        try:
+            buf = torch.empty((M * world, rows), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(buf, Y); fence()
+            t1 = time.perf_counter(); dist.all_gather_into_tensor(buf, Y); fence()
+            full_gather_ms = (time.perf_counter() - t1) * 1e3
+            del buf
+        except Exception:
+            full_gather_ms = None
+
+    verify = None
+    if rank == 0 and not args.no_verify:
+        import oracle
+        A = oracle.dn(n) if which == sri.OP_DN else oracle.integration(n)[0]
+        idx = torch.arange(0, M, max(M // 256, 1), device=dev)[:256]
+        Xs = np.asfortranarray(X[idx].cpu().numpy().T)
+        Ys = np.asfortranarray(Y[idx].cpu().numpy().T)
+        Yr = oracle.apply(A, Xs, threads=0)
+        verify = float(np.linalg.norm(Ys - Yr) / np.linalg.norm(Yr))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rods * world / (elapsed / args.steps)
+        flops = 8.0 * rows * rows * rods                    # per launch, algorithmic
+        alg_bytes = 64.0 * rows * rods + 8.0 * rows * rows
+        achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                rec = json.load(open(tp))
+                if rec.get("n") == n and rec.get("rods") == rods and rec.get("operator") == args.operator:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rod-states/sec (D_N.X apply, fp64) at N=256; % MI355X fp64 MFMA peak" if (n == 256 and which == sri.OP_DN)
+                      else f"rod-states/sec ({args.operator} apply, fp64) at N={n}",
+            "value": value, "unit": "rod-states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={n}, batch={rods} rods x 4 state columns per GPU, fp64, {args.operator} apply"
+                                   + (f", {world} GPUs sharded on the batch axis, RCCL all-gather of {args.gather} state" if world > 1 else ""),
+                       "N": n, "rods_per_gpu": rods, "state_columns": 4, "operator": args.operator,
+                       "kernel": op.last_kernel, "gather": args.gather if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "hbm_algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_frac_of_8TBps": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "parity_fro_rel_err_sampled": verify,
+        }
+        if full_gather_ms is not None:
+            out["full_panel_allgather_ms"] = full_gather_ms
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+"""MI355X-native spectral-integration hot path — Python host mirror over the C ABI.
+
+The product is ``libsri_hip.so`` (``csrc/``: C++ host formers + the gfx950 MFMA-fp64 apply kernel,
+C ABI declared in ``include/sri_capi.h``).  This package is a thin ctypes binding of that ABI with
+the reference's own names (``ComputeChebyshevPoints``, ``GetCoefficients_c``, ``getDn`` —
+``/root/reference/include/chebyshev_differentiation.h:19-108``) plus the batched apply that
+replaces ``main.cpp:172`` / ``main.cpp:97``.  PyTorch is used only for device memory and streams.
+
+There is NO CPU fallback for the apply: if the shared library is missing, or no gfx950 device is
+present, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+__all__ = [
+    "SriError", "build_library", "library_path", "load_library",
+    "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
+    "SpectralApply", "OP_DN", "OP_DNN_INV", "OP_DNN",
+]
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_LIB_NAME = "libsri_hip.so"
+
+OP_DN, OP_DNN_INV, OP_DNN = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes): every symbol include/sri_capi.h declares.
+_u32, _sz, _dbl, _int, _vp = C.c_uint32, C.c_size_t, C.c_double, C.c_int, C.c_void_p
+C_ABI = {
+    "sri_cheb_points": (_int, [_u32, _dbl, _dp]),
+    "sri_cheb_coeffs": (_int, [_u32, _dp]),
+    "sri_cheb_dn": (_int, [_u32, _dp, _sz]),
+    "sri_cheb_blocks": (_int, [_u32, _dp, _sz, _dp, _sz, _dp]),
+    "sri_cheb_integration": (_int, [_u32, _dp, _sz, _dp]),
+    "sri_ivp": (_int, [_u32, _u32, _dp, _dp, _dp, _sz]),
+    "sri_apply_create": (_int, [C.POINTER(_vp), _u32, _int, _int]),
+    "sri_apply_create_matrix": (_int, [C.POINTER(_vp), _u32, _dp, _sz, _int]),
+    "sri_apply_dim": (_int, [_vp, C.POINTER(_u32)]),
+    "sri_apply": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp]),
+    "sri_integrate": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
+    "sri_apply_destroy": (_int, [_vp]),
+    "sri_apply_last_kernel": (C.c_char_p, [_vp]),
+    "sri_strerror": (C.c_char_p, [_int]),
+    "sri_last_hip_error": (_int, []),
+    "sri_abi_version": (_int, []),
+    "sri_device_count": (_int, [C.POINTER(_int)]),
+}
+
+
+class SriError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        msg = "?"
+        if _lib is not None:
+            msg = _lib.sri_strerror(status).decode()
+            if status == -4:
+                msg += f" (hipError {_lib.sri_last_hip_error()})"
+        super().__init__(f"{what}: {msg} [sri_status {status}]")
+
+
+def library_path() -> str:
+    return os.path.join(_PKG, _LIB_NAME)
+
+
+def build_library(force: bool = False) -> str:
+    """Compile ``libsri_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+
+    csrc = os.path.join(_PKG, "csrc")
+    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+def load_library() -> C.CDLL:
+    """dlopen the product library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: the HIP extension has not been built "
+                f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {os.path.join(_PKG, 'csrc')}`). "
+                "There is no CPU fallback for the spectral apply.")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+        # libhsa-runtime64.so.1.  Import torch FIRST so that our DT_NEEDED entries resolve (by
+        # soname) to the copies torch already mapped; loading /opt/rocm's copies next to torch's
+        # gives two runtimes fighting over the device ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(path)
+        for name, (res, args) in C_ABI.items():
+            fn = getattr(lib, name)   # AttributeError if the library does not export the symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _chk(status: int, what: str) -> None:
+    if status != 0:
+        raise SriError(status, what)
+
+
+def _fmat(rows: int, cols: int) -> np.ndarray:
+    return np.zeros((rows, cols), dtype=np.float64, order="F")
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+# ------------------------------------------------------------------------------------------------
+# Host formers — same names as the reference header (chebyshev_differentiation.h)
+# ------------------------------------------------------------------------------------------------
+def ComputeChebyshevPoints(n: int, L: float = 1.0) -> np.ndarray:
+    """``ComputeChebyshevPoints<N, L>()`` (chebyshev_differentiation.h:19-30)."""
+    x = np.zeros(int(n), dtype=np.float64)
+    _chk(load_library().sri_cheb_points(n, L, _p(x)), "sri_cheb_points")
+    return x
+
+
+def GetCoefficients_c(n: int) -> np.ndarray:
+    """``GetCoefficients_c<N>()`` (chebyshev_differentiation.h:37-52)."""
+    c = np.zeros(int(n), dtype=np.float64)
+    _chk(load_library().sri_cheb_coeffs(n, _p(c)), "sri_cheb_coeffs")
+    return c
+
+
+def getDn(n: int) -> np.ndarray:
+    """``getDn<N>()`` (chebyshev_differentiation.h:59-108): column-major N x N ndarray."""
+    D = _fmat(n, n)
+    _chk(load_library().sri_cheb_dn(n, _p(D), n), "sri_cheb_dn")
+    return D
+
+
+def dn_blocks(D: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """``Dn_NN``, ``Dn_IN`` of main.cpp:94-95."""
+    D = np.asfortranarray(D, dtype=np.float64)
+    n = D.shape[0]
+    Dnn, Din = _fmat(n - 1, n - 1), np.zeros(n - 1)
+    _chk(load_library().sri_cheb_blocks(n, _p(D), n, _p(Dnn), n - 1, _p(Din)), "sri_cheb_blocks")
+    return Dnn, Din
+
+
+def integration_matrix(n: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``(Dn_NN.inverse(), Dn_IN)`` of main.cpp:157-160."""
+    Dinv, Din = _fmat(n - 1, n - 1), np.zeros(n - 1)
+    _chk(load_library().sri_cheb_integration(n, _p(Dinv), n - 1, _p(Din)), "sri_cheb_integration")
+    return Dinv, Din
+
+
+def ivp(Din: np.ndarray, x_base: np.ndarray) -> np.ndarray:
+    """Initial-value term ``Dn_IN * x_base^T`` (main.cpp:109, 162-164)."""
+    Din = np.ascontiguousarray(Din, dtype=np.float64)
+    x_base = np.ascontiguousarray(x_base, dtype=np.float64)
+    out = _fmat(Din.shape[0], x_base.shape[0])
+    _chk(load_library().sri_ivp(Din.shape[0], x_base.shape[0], _p(Din), _p(x_base), _p(out), Din.shape[0]), "sri_ivp")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The batched apply
+# ------------------------------------------------------------------------------------------------
+class SpectralApply:
+    """Device-resident spectral operator: ``Y = A @ X`` for a panel of rod-state columns.
+
+    Panels are torch CUDA tensors of dtype float64 and shape ``(..., rows)`` whose last dimension
+    is contiguous — e.g. ``(B, s, N)``: rod, state component, node.  In memory that IS the
+    reference's column-major ``N x (s*B)`` matrix (each state column = N contiguous doubles,
+    main.cpp:113,130-133), so no transposition happens anywhere.
+    """
+
+    def __init__(self, n: int, which: int = OP_DN, device: int = 0, matrix: Optional[np.ndarray] = None):
+        lib = load_library()
+        self._h = _vp()
+        self.device = int(device)
+        self.n = int(n)
+        self.which = which
+        if matrix is not None:
+            A = np.asfortranarray(matrix, dtype=np.float64)
+            assert A.shape[0] == A.shape[1]
+            _chk(lib.sri_apply_create_matrix(C.byref(self._h), A.shape[0], _p(A), A.shape[0], self.device),
+                 "sri_apply_create_matrix")
+        else:
+            _chk(lib.sri_apply_create(C.byref(self._h), self.n, which, self.device), "sri_apply_create")
+        r = _u32()
+        _chk(lib.sri_apply_dim(self._h, C.byref(r)), "sri_apply_dim")
+        self.rows = int(r.value)
+
+    # -- device path ---------------------------------------------------------------------------
+    def _panel(self, t, name):
+        import torch
+
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
+            raise TypeError(f"{name} must be a float64 CUDA tensor")
+        if t.shape[-1] != self.rows:
+            raise ValueError(f"{name}: last dimension {t.shape[-1]} != operator rows {self.rows}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous (columns of {self.rows} doubles)")
+        if t.device.index != self.device:
+            raise ValueError(f"{name} is on cuda:{t.device.index}, operator on cuda:{self.device}")
+        return t
+
+    def apply(self, X, out=None, stream=None):
+        """``Y = A @ X`` on the GPU (enqueued on torch's current stream unless ``stream`` is given)."""
+        import torch
+
+        X = self._panel(X, "X")
+        Y = torch.empty_like(X) if out is None else self._panel(out, "out")
+        if Y.shape != X.shape:
+            raise ValueError("out must have X's shape")
+        M = X.numel() // self.rows
+        s = torch.cuda.current_stream(X.device).cuda_stream if stream is None else stream
+        _chk(load_library().sri_apply(self._h, X.data_ptr(), self.rows, Y.data_ptr(), self.rows, M, s), "sri_apply")
+        return Y
+
+    __call__ = apply
+
+    def integrate(self, B, x_base, out=None, stream=None):
+        """``Y = Dnn_inv @ (B - Dn_IN x_base^T)`` (main.cpp:172), operator must be ``OP_DNN_INV``.
+
+        ``x_base`` holds the base-node value of every column: shape ``B.shape[:-1]``.
+        """
+        import torch
+
+        B = self._panel(B, "B")
+        if not (x_base.is_cuda and x_base.dtype == torch.float64 and x_base.is_contiguous()
+                and tuple(x_base.shape) == tuple(B.shape[:-1])):
+            raise ValueError("x_base must be a contiguous float64 CUDA tensor of shape B.shape[:-1]")
+        Y = torch.empty_like(B) if out is None else self._panel(out, "out")
+        M = B.numel() // self.rows
+        s = torch.cuda.current_stream(B.device).cuda_stream if stream is None else stream
+        _chk(load_library().sri_integrate(self._h, B.data_ptr(), self.rows, x_base.data_ptr(), Y.data_ptr(),
+                                          self.rows, M, s), "sri_integrate")
+        return Y
+
+    # -- host convenience (PCIe-inclusive) -------------------------------------------------------
+    def apply_host(self, X: np.ndarray) -> np.ndarray:
+        """``Y = A @ X`` for a column-major host matrix ``rows x M`` (staged through the GPU)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.shape[0] != self.rows:
+            raise ValueError(f"X has {X.shape[0]} rows, operator has {self.rows}")
+        Y = _fmat(*X.shape)
+        _chk(load_library().sri_apply_host(self._h, _p(X), self.rows, _p(Y), self.rows, X.shape[1]), "sri_apply_host")
+        return Y
+
+    @property
+    def last_kernel(self) -> str:
+        return load_library().sri_apply_last_kernel(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load_library().sri_apply_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

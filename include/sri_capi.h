@@ -1,0 +1,137 @@
+/*
+ * sri_capi.h — C ABI of libsri_hip.so, the MI355X-native spectral-integration hot path.
+ *
+ * The reference (aGotelli/experimental_gpu_programming_for_a_spectral_numerical_integration)
+ * has no plugin / FFI boundary: its API is three header-only templates in
+ * include/chebyshev_differentiation.h called straight from main.cpp.  This header is the
+ * boundary a maintainer would bind instead; include/chebyshev_differentiation.h in THIS repo
+ * re-exposes the reference's three template signatures on top of it.
+ *
+ * Conventions
+ *   - every matrix is COLUMN-MAJOR fp64 with an explicit leading dimension (Eigen's default
+ *     storage, so `M.data()`, `M.outerStride()` can be passed as is);
+ *   - a "state panel" X is rows x M: one column per (rod, state component), rods concatenated
+ *     along columns (main.cpp:113,130-133: Q_stack[c*(N-1)+i] == column-major (N-1) x 4);
+ *   - all entry points return 0 (SRI_OK) or a negative sri_status; nothing throws across the ABI;
+ *   - host formers are re-entrant; one sri_apply_t per device, not to be driven from two threads
+ *     at once without external locking;
+ *   - sri_apply() takes DEVICE pointers and only enqueues work on the given HIP stream
+ *     (no allocation, no synchronisation: it is graph-capturable).
+ *
+ * file:line citations are relative to the reference tree.
+ */
+#ifndef SRI_CAPI_H
+#define SRI_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRI_ABI_VERSION 1
+
+typedef enum sri_status {
+    SRI_OK = 0,
+    SRI_EINVAL = -1,       /* null pointer, n < 2, leading dimension too small ...            */
+    SRI_ENOMEM = -2,       /* host or device allocation failed                                */
+    SRI_ESINGULAR = -3,    /* zero pivot while inverting Dn_NN                                 */
+    SRI_EHIP = -4,         /* a HIP runtime call failed (sri_last_hip_error() has the code)   */
+    SRI_ENODEVICE = -5,    /* no gfx950 device / bad device ordinal                           */
+    SRI_EUNSUPPORTED = -6  /* valid request this build cannot serve                           */
+} sri_status;
+
+/* Which constant left-hand matrix an apply handle holds. */
+typedef enum sri_operator {
+    SRI_OP_DN = 0,       /* D_N, N x N                    (chebyshev_differentiation.h:59-108; used as
+                            I_s (x) D_N at main.cpp:97)                                          */
+    SRI_OP_DNN_INV = 1,  /* Dn_NN^-1, (N-1) x (N-1)       (main.cpp:158-159; applied at main.cpp:172) */
+    SRI_OP_DNN = 2       /* Dn_NN,    (N-1) x (N-1)       (main.cpp:94, 158)                          */
+} sri_operator;
+
+/* ---------------------------------------------------------------------------------------- */
+/* Host formers (O(N^2) / O(N^3) once per N; IEEE fp64, libm cos on the host so that D_N is   */
+/* bit-identical to what the reference forms — SURVEY.md §7 H3).                              */
+/* ---------------------------------------------------------------------------------------- */
+
+/* ComputeChebyshevPoints<N, L>()  chebyshev_differentiation.h:19-30.
+ * x[j] = (L/2)(1 + cos(pi j/(n-1))), j = 0..n-1, descending from L to 0.  x: n doubles. */
+int sri_cheb_points(uint32_t n, double L, double *x);
+
+/* GetCoefficients_c<N>()  chebyshev_differentiation.h:37-52.
+ * c[i] = (-1)^i * (2 at both ends, 1 elsewhere).  c: n doubles. */
+int sri_cheb_coeffs(uint32_t n, double *c);
+
+/* getDn<N>()  chebyshev_differentiation.h:59-108.
+ * D: n x n column-major, leading dimension ld >= n. */
+int sri_cheb_dn(uint32_t n, double *D, size_t ld);
+
+/* Block slicing  main.cpp:94-95, 158, 160.
+ * Dnn = D[0:n-1, 0:n-1] (ldnn >= n-1), Din = D[0:n-1, n-1] (n-1 doubles).  Either output may be
+ * NULL. */
+int sri_cheb_blocks(uint32_t n, const double *D, size_t ld, double *Dnn, size_t ldnn, double *Din);
+
+/* Spectral integration matrix  main.cpp:157-160:  Dnn_inv = (getDn<n>()[0:n-1,0:n-1])^-1 by
+ * partial-pivot LU (what Eigen's .inverse() does for sizes > 4), plus the base-node influence
+ * column Din (may be NULL).  Dnn_inv: (n-1) x (n-1), ld >= n-1. */
+int sri_cheb_integration(uint32_t n, double *Dnn_inv, size_t ld, double *Din);
+
+/* Initial-value term  main.cpp:162-164 (positions), main.cpp:100,109 (quaternions):
+ * ivp(i,c) = Din[i] * x_base[c];  ivp is m x s column-major, ld >= m. */
+int sri_ivp(uint32_t m, uint32_t s, const double *Din, const double *x_base, double *ivp, size_t ld);
+
+/* ---------------------------------------------------------------------------------------- */
+/* The apply:  Y[rows x M] = A[rows x rows] * X[rows x M]   (main.cpp:172; Kronecker form      */
+/* main.cpp:97).  A is formed on the host once, packed into MFMA-fragment order and kept on    */
+/* the device by the handle; X and Y are device buffers owned by the caller.                  */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct sri_apply_handle sri_apply_t;
+
+/* Form operator `which` for n Chebyshev nodes and upload it to HIP device `device`. */
+int sri_apply_create(sri_apply_t **out, uint32_t n, int which, int device);
+
+/* Same, for a caller-supplied square matrix A (rows x rows, column-major, lda >= rows). */
+int sri_apply_create_matrix(sri_apply_t **out, uint32_t rows, const double *A, size_t lda, int device);
+
+/* rows (= cols) of the operator held by the handle: n for SRI_OP_DN, n-1 otherwise. */
+int sri_apply_dim(const sri_apply_t *h, uint32_t *rows);
+
+/* Enqueue Y = A * X on `hip_stream` (a hipStream_t, NULL = the device's null stream).
+ * dX, dY: device pointers, column-major rows x M, ldx, ldy >= rows.  X and Y must not overlap.
+ * M may be any value >= 0; no alignment requirement (16-byte aligned pointers with even leading
+ * dimensions and rows % 16 == 0 take the LDS-DMA fast path). */
+int sri_apply(sri_apply_t *h, const double *dX, size_t ldx, double *dY, size_t ldy, size_t M,
+              void *hip_stream);
+
+/* Position/quaternion integration in one call, main.cpp:172 batched:
+ *   Y = Dnn_inv * (B - Din * x_base^T)
+ * for a handle created with SRI_OP_DNN_INV.  dB: (n-1) x M, d_x_base: M doubles (the base-node
+ * value of every column), all device pointers.  The rank-1 initial-value term is applied as
+ * Y -= (Dnn_inv*Din) * x_base^T in the kernel epilogue. */
+int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
+                  double *dY, size_t ldy, size_t M, void *hip_stream);
+
+/* Convenience for callers holding HOST buffers: stages X through device memory, applies,
+ * copies Y back, synchronises.  (PCIe-inclusive; never what bench.py times.) */
+int sri_apply_host(sri_apply_t *h, const double *X, size_t ldx, double *Y, size_t ldy, size_t M);
+
+int sri_apply_destroy(sri_apply_t *h);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Introspection / diagnostics                                                              */
+/* ---------------------------------------------------------------------------------------- */
+
+/* Name of the kernel variant the last sri_apply()/sri_integrate() on this handle launched
+ * (static string, e.g. "sri_apply_mfma_f64<256x64,dma>"). */
+const char *sri_apply_last_kernel(const sri_apply_t *h);
+
+const char *sri_strerror(int status);
+int sri_last_hip_error(void);
+int sri_abi_version(void);
+int sri_device_count(int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRI_CAPI_H */

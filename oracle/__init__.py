@@ -1,0 +1,214 @@
+"""CPU ORACLE — test infrastructure, NOT product code.
+
+ctypes binding of ``oracle/libsri_oracle.so`` (built by ``make -C oracle`` from
+``oracle/sri_oracle.c``), the plain-C restatement of the reference's spectral-integration hot
+path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package never does.
+
+PARITY UNPINNED — the reference has no tests/golden vectors and cannot be built in this image;
+see the header of ``sri_oracle.c`` and DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsri_oracle.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
+        for s in ("sri_oracle.c", "sri_oracle_mt.c", "Makefile")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsri_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        for name in dir(_Sig):
+            if name.startswith("sri_"):
+                fn = getattr(_lib, name)
+                fn.restype = C.c_int
+                fn.argtypes = getattr(_Sig, name)
+    return _lib
+
+
+class _Sig:
+    u32, sz, dbl, i = C.c_uint32, C.c_size_t, C.c_double, C.c_int
+    sri_oracle_points = [u32, dbl, _dp]
+    sri_oracle_coeffs = [u32, _dp]
+    sri_oracle_dn = [u32, _dp, sz]
+    sri_oracle_blocks = [u32, _dp, sz, _dp, sz, _dp]
+    sri_oracle_inverse = [u32, _dp, sz, _dp, sz]
+    sri_oracle_integration = [u32, _dp, sz, _dp]
+    sri_oracle_ivp = [u32, u32, _dp, _dp, _dp, sz]
+    sri_oracle_apply = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz]
+    sri_oracle_apply_dot = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz]
+    sri_oracle_apply_mt = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz, i]
+    sri_oracle_integrate = [u32, _dp, sz, _dp, _dp, sz, _dp, _dp, sz, sz]
+    sri_oracle_legendre_basis = [dbl, u32, _dp]
+    sri_oracle_strain = [dbl, u32, u32, _dp, _dp]
+    sri_oracle_integrate_quaternions = [u32, _dp, u32, u32, _dp, _dp]
+    sri_oracle_position_rhs = [u32, _dp, sz, _dp, sz]
+    sri_oracle_integrate_position = [u32, _dp, _dp, _dp]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.float64
+    return a.ctypes.data_as(_dp)
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def _fmat(rows: int, cols: int) -> np.ndarray:
+    """Column-major (Fortran-order) rows x cols matrix, as Eigen stores it."""
+    return np.zeros((rows, cols), dtype=np.float64, order="F")
+
+
+def _ld(a: np.ndarray) -> int:
+    assert a.flags.f_contiguous or a.ndim == 1
+    return a.shape[0]
+
+
+# ---- chebyshev_differentiation.h ------------------------------------------------------------
+def points(n: int, L: float = 1.0) -> np.ndarray:
+    x = np.zeros(n)
+    _chk(lib().sri_oracle_points(n, L, _p(x)), "points")
+    return x
+
+
+def coeffs(n: int) -> np.ndarray:
+    c = np.zeros(n)
+    _chk(lib().sri_oracle_coeffs(n, _p(c)), "coeffs")
+    return c
+
+
+def dn(n: int) -> np.ndarray:
+    D = _fmat(n, n)
+    _chk(lib().sri_oracle_dn(n, _p(D), n), "dn")
+    return D
+
+
+# ---- main.cpp consumers ---------------------------------------------------------------------
+def blocks(D: np.ndarray):
+    n = D.shape[0]
+    D = np.asfortranarray(D)
+    Dnn, Din = _fmat(n - 1, n - 1), np.zeros(n - 1)
+    _chk(lib().sri_oracle_blocks(n, _p(D), n, _p(Dnn), n - 1, _p(Din)), "blocks")
+    return Dnn, Din
+
+
+def inverse(A: np.ndarray) -> np.ndarray:
+    A = np.asfortranarray(A, dtype=np.float64)
+    m = A.shape[0]
+    Ai = _fmat(m, m)
+    _chk(lib().sri_oracle_inverse(m, _p(A), m, _p(Ai), m), "inverse")
+    return Ai
+
+
+def integration(n: int):
+    """(Dn_NN^-1, Dn_IN) of main.cpp:157-160."""
+    Dinv, Din = _fmat(n - 1, n - 1), np.zeros(n - 1)
+    _chk(lib().sri_oracle_integration(n, _p(Dinv), n - 1, _p(Din)), "integration")
+    return Dinv, Din
+
+
+def ivp(Din: np.ndarray, x_base: np.ndarray) -> np.ndarray:
+    m, s = Din.shape[0], x_base.shape[0]
+    out = _fmat(m, s)
+    _chk(lib().sri_oracle_ivp(m, s, _p(np.ascontiguousarray(Din)), _p(np.ascontiguousarray(x_base)), _p(out), m), "ivp")
+    return out
+
+
+def apply(A: np.ndarray, X: np.ndarray, *, dot: bool = False, threads: int = 1) -> np.ndarray:
+    """Y = A @ X with the reference's arithmetic (main.cpp:172 / :97). X, Y column-major."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    r, k = A.shape
+    assert X.shape[0] == k
+    M = X.shape[1]
+    Y = _fmat(r, M)
+    if dot:
+        _chk(lib().sri_oracle_apply_dot(r, k, _p(A), r, _p(X), k, _p(Y), r, M), "apply_dot")
+    elif threads != 1:
+        _chk(lib().sri_oracle_apply_mt(r, k, _p(A), r, _p(X), k, _p(Y), r, M, threads), "apply_mt")
+    else:
+        _chk(lib().sri_oracle_apply(r, k, _p(A), r, _p(X), k, _p(Y), r, M), "apply")
+    return Y
+
+
+def integrate(Dinv: np.ndarray, Din: np.ndarray, B: np.ndarray, x_base: np.ndarray) -> np.ndarray:
+    """Y = Dinv @ (B - Din x_base^T), batched main.cpp:172."""
+    Dinv = np.asfortranarray(Dinv)
+    B = np.asfortranarray(B)
+    m, M = B.shape
+    Y = _fmat(m, M)
+    _chk(lib().sri_oracle_integrate(m, _p(Dinv), m, _p(np.ascontiguousarray(Din)), _p(B), m,
+                                    _p(np.ascontiguousarray(x_base)), _p(Y), m, M), "integrate")
+    return Y
+
+
+def max_threads() -> int:
+    lib()
+    _lib.sri_oracle_max_threads.restype = C.c_int
+    _lib.sri_oracle_max_threads.argtypes = []
+    return int(_lib.sri_oracle_max_threads())
+
+
+# ---- rod model (config 1) -------------------------------------------------------------------
+def legendre_basis(X: float, ne: int) -> np.ndarray:
+    P = np.zeros(ne)
+    _chk(lib().sri_oracle_legendre_basis(X, ne, _p(P)), "legendre_basis")
+    return P
+
+
+def strain(X: float, qe: np.ndarray, na: int = 3, ne: int = 3) -> np.ndarray:
+    K = np.zeros(na)
+    _chk(lib().sri_oracle_strain(X, na, ne, _p(np.ascontiguousarray(qe, dtype=np.float64)), _p(K)), "strain")
+    return K
+
+
+def integrate_quaternions(n: int, qe: np.ndarray, q_init=None, na: int = 3, ne: int = 3) -> np.ndarray:
+    """Q_stack of main.cpp:91-118 as a column-major (n-1) x 4 matrix (w, x, y, z)."""
+    Q = np.zeros(4 * (n - 1))
+    qi = None if q_init is None else _p(np.ascontiguousarray(q_init, dtype=np.float64))
+    _chk(lib().sri_oracle_integrate_quaternions(n, _p(np.ascontiguousarray(qe, dtype=np.float64)), na, ne, qi, _p(Q)),
+         "integrate_quaternions")
+    return np.asfortranarray(Q.reshape(4, n - 1).T)
+
+
+def position_rhs(Q: np.ndarray) -> np.ndarray:
+    Q = np.asfortranarray(Q)
+    m = Q.shape[0]
+    b = _fmat(m, 3)
+    _chk(lib().sri_oracle_position_rhs(m, _p(Q), m, _p(b), m), "position_rhs")
+    return b
+
+
+def integrate_position(n: int, Q: np.ndarray, r_init=None) -> np.ndarray:
+    """r_stack of main.cpp:145-176 as a column-major (n-1) x 3 matrix."""
+    Q = np.asfortranarray(Q)
+    r = _fmat(n - 1, 3)
+    ri = None if r_init is None else _p(np.ascontiguousarray(r_init, dtype=np.float64))
+    _chk(lib().sri_oracle_integrate_position(n, _p(Q), ri, _p(r)), "integrate_position")
+    return r
+
+
+QE_MAIN_CPP = np.array([0, 0, 0, 1.2877691307032, -1.63807499160786, 0.437406679142598, 0, 0, 0], dtype=np.float64)
+"""The hard-coded strain coordinates of main.cpp:187-195."""

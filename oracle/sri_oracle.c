@@ -1,0 +1,395 @@
+/*
+ * sri_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement, operation for operation, of the reference's spectral-integration hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product library (libsri_hip.so) never links, calls or falls back to anything in here.
+ *
+ * PARITY UNPINNED: the reference (aGotelli/experimental_gpu_programming_for_a_spectral_numerical_
+ * integration) ships no tests, golden vectors or fixtures, and cannot be compiled in this image
+ * (it needs Eigen >= 3.4 and Boost.Math, both absent; no network).  This oracle is therefore
+ * pinned only by (i) the closed-form known answers of the reference's own documentation
+ * (materials/rod_modeling.pdf eq. B.7, B.12, B.14, B.16), (ii) structural identities, and (iii) the
+ * survey-computed anchors of SURVEY.md Appendix B.  See DESIGN.md "Oracle".
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * Third-party arithmetic that lives outside the reference tree is restated from the library's
+ * published algorithm and named where used:
+ *   - Eigen 3.4 (un-vendored, CMakeLists.txt:11): PartialPivLU inverse, coefficient-wise
+ *     rowwise().sum(), dense product, Quaternion::toRotationMatrix.
+ *   - Boost.Math legendre_p (utilities.h:59): three-term recurrence.
+ *   - libm cos / pow.
+ *
+ * Storage: every matrix is COLUMN-MAJOR (Eigen's default), leading dimension given explicitly.
+ * Compile with -ffp-contract=off so no FMA contraction changes the rounding sequence.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define SRI_OK 0
+#define SRI_EINVAL (-1)
+#define SRI_ENOMEM (-2)
+#define SRI_ESINGULAR (-3)
+
+/* ------------------------------------------------------------------------------------------ */
+/* include/chebyshev_differentiation.h:19-30  ComputeChebyshevPoints<N, L>()                   */
+/*   x_j = (double(L)/2) * (1 + cos(M_PI * double(j) / double(N-1)))   (h:26)                  */
+/* descending: x_0 = L, x_{N-1} = 0.                                                          */
+int sri_oracle_points(uint32_t n, double L, double *x)
+{
+    if (n < 2 || !x) return SRI_EINVAL;
+    const double half = L / 2;
+    for (uint32_t j = 0; j < n; ++j)
+        x[j] = half * (1 + cos(M_PI * (double)j / (double)(n - 1)));
+    return SRI_OK;
+}
+
+/* include/chebyshev_differentiation.h:37-52  GetCoefficients_c<N>()                           */
+/*   gain = 2 at i == 0 or i == N-1, else 1 (h:45);  c_i = pow(-1, i) * gain (h:48)            */
+int sri_oracle_coeffs(uint32_t n, double *c)
+{
+    if (n < 2 || !c) return SRI_EINVAL;
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned gain = (i == 0 || i == n - 1) ? 2u : 1u;
+        c[i] = pow(-1.0, (double)i) * (double)gain;
+    }
+    return SRI_OK;
+}
+
+/* include/chebyshev_differentiation.h:59-108  getDn<N>()                                      */
+/*   X(i,:) = x_i                                   (h:69-71)                                  */
+/*   C(i,j) = c_i / c_j                             (h:81-86)                                  */
+/*   dX = X - X^T + I  -> (x_i - x_j) + delta_ij    (h:89)                                     */
+/*   Dn(i,j) = C(i,j) / dX(i,j)  for ALL i,j        (h:96-100)   (diagonal is 1/1 = 1)         */
+/*   Dn.diagonal() -= Dn.rowwise().sum()            (h:104)                                    */
+/* The last line is evaluated by Eigen coefficient-wise on a strided (row) block: a sequential */
+/* left-to-right sum over the whole row INCLUDING the provisional diagonal 1, then              */
+/* D_ii = 1 - sum.                                                                            */
+int sri_oracle_dn(uint32_t n, double *D, size_t ld)
+{
+    if (n < 2 || !D || ld < n) return SRI_EINVAL;
+    double *x = (double *)malloc(sizeof(double) * n);
+    double *c = (double *)malloc(sizeof(double) * n);
+    if (!x || !c) { free(x); free(c); return SRI_ENOMEM; }
+    sri_oracle_points(n, 1.0, x);
+    sri_oracle_coeffs(n, c);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (uint32_t j = 0; j < n; ++j) {
+            const double Cij = c[i] / c[j];
+            const double dXij = (x[i] - x[j]) + (i == j ? 1.0 : 0.0);
+            D[i + j * ld] = Cij / dXij;
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        double s = D[i + 0 * ld];
+        for (uint32_t j = 1; j < n; ++j) s = s + D[i + j * ld];
+        D[i + i * ld] -= s;
+    }
+    free(x); free(c);
+    return SRI_OK;
+}
+
+/* main.cpp:94-95, 158, 160  block slicing                                                    */
+/*   Dn_NN = Dn.block<N-1,N-1>(0,0) ; Dn_IN = Dn.block<N-1,1>(0,N-1)                           */
+int sri_oracle_blocks(uint32_t n, const double *D, size_t ld, double *Dnn, size_t ldnn, double *Din)
+{
+    if (n < 2 || !D || ld < n) return SRI_EINVAL;
+    const uint32_t m = n - 1;
+    if (Dnn) {
+        if (ldnn < m) return SRI_EINVAL;
+        for (uint32_t j = 0; j < m; ++j)
+            for (uint32_t i = 0; i < m; ++i) Dnn[i + j * ldnn] = D[i + j * ld];
+    }
+    if (Din)
+        for (uint32_t i = 0; i < m; ++i) Din[i] = D[i + (size_t)m * ld];
+    return SRI_OK;
+}
+
+/* Dense inverse, m x m, column-major.  Follows what `.inverse()` does in Eigen 3.4 for m > 4   */
+/* (main.cpp:113, 159): PartialPivLU — at step k pick the FIRST row of largest |entry| in       */
+/* column k at or below the diagonal, swap, scale the sub-column by 1/pivot... (Eigen divides   */
+/* the sub-column by the pivot, `lu.col(k).tail(rrows) /= lu.coeff(k,k)`), rank-1 update of the */
+/* trailing block; then inverse = U^-1 L^-1 P by a unit-lower forward substitution and an upper */
+/* back substitution on the permuted identity, column by column.                               */
+int sri_oracle_inverse(uint32_t m, const double *A, size_t lda, double *Ainv, size_t ldi)
+{
+    if (m < 1 || !A || !Ainv || lda < m || ldi < m) return SRI_EINVAL;
+    double *lu = (double *)malloc(sizeof(double) * (size_t)m * m);
+    uint32_t *piv = (uint32_t *)malloc(sizeof(uint32_t) * m);
+    if (!lu || !piv) { free(lu); free(piv); return SRI_ENOMEM; }
+    for (uint32_t j = 0; j < m; ++j)
+        for (uint32_t i = 0; i < m; ++i) lu[i + (size_t)j * m] = A[i + j * lda];
+    int rc = SRI_OK;
+    for (uint32_t k = 0; k < m; ++k) {
+        uint32_t p = k; double big = fabs(lu[k + (size_t)k * m]);
+        for (uint32_t i = k + 1; i < m; ++i) {
+            const double v = fabs(lu[i + (size_t)k * m]);
+            if (v > big) { big = v; p = i; }
+        }
+        piv[k] = p;
+        if (big == 0.0) { rc = SRI_ESINGULAR; continue; }
+        if (p != k)
+            for (uint32_t j = 0; j < m; ++j) {
+                const double t = lu[k + (size_t)j * m]; lu[k + (size_t)j * m] = lu[p + (size_t)j * m]; lu[p + (size_t)j * m] = t;
+            }
+        const double pivot = lu[k + (size_t)k * m];
+        for (uint32_t i = k + 1; i < m; ++i) lu[i + (size_t)k * m] /= pivot;
+        for (uint32_t j = k + 1; j < m; ++j) {
+            const double ukj = lu[k + (size_t)j * m];
+            for (uint32_t i = k + 1; i < m; ++i) lu[i + (size_t)j * m] -= lu[i + (size_t)k * m] * ukj;
+        }
+    }
+    if (rc == SRI_OK) {
+        /* Ainv = P * I  (apply the row transpositions in order), then L then U solves. */
+        for (uint32_t j = 0; j < m; ++j)
+            for (uint32_t i = 0; i < m; ++i) Ainv[i + j * ldi] = (i == j) ? 1.0 : 0.0;
+        for (uint32_t k = 0; k < m; ++k)
+            if (piv[k] != k)
+                for (uint32_t j = 0; j < m; ++j) {
+                    const double t = Ainv[k + j * ldi]; Ainv[k + j * ldi] = Ainv[piv[k] + j * ldi]; Ainv[piv[k] + j * ldi] = t;
+                }
+        for (uint32_t j = 0; j < m; ++j) {
+            double *b = Ainv + j * ldi;
+            for (uint32_t k = 0; k < m; ++k) {            /* unit lower, column-oriented */
+                const double bk = b[k];
+                if (bk != 0.0)
+                    for (uint32_t i = k + 1; i < m; ++i) b[i] -= bk * lu[i + (size_t)k * m];
+            }
+            for (uint32_t kk = m; kk-- > 0;) {            /* upper, column-oriented */
+                b[kk] /= lu[kk + (size_t)kk * m];
+                const double bk = b[kk];
+                for (uint32_t i = 0; i < kk; ++i) b[i] -= bk * lu[i + (size_t)kk * m];
+            }
+        }
+    }
+    free(lu); free(piv);
+    return rc;
+}
+
+/* main.cpp:157-160  the spectral INTEGRATION matrix and the base-node influence column         */
+/*   Dn = getDn<N>(); Dn_NN = block; Dn_NN_inv = Dn_NN.inverse(); Dn_IN = block                 */
+int sri_oracle_integration(uint32_t n, double *Dnn_inv, size_t ld, double *Din)
+{
+    if (n < 2 || !Dnn_inv || ld < n - 1) return SRI_EINVAL;
+    const uint32_t m = n - 1;
+    double *D = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *Dnn = (double *)malloc(sizeof(double) * (size_t)m * m);
+    if (!D || !Dnn) { free(D); free(Dnn); return SRI_ENOMEM; }
+    int rc = sri_oracle_dn(n, D, n);
+    if (rc == SRI_OK) rc = sri_oracle_blocks(n, D, n, Dnn, m, Din);
+    if (rc == SRI_OK) rc = sri_oracle_inverse(m, Dnn, m, Dnn_inv, ld);
+    free(D); free(Dnn);
+    return rc;
+}
+
+/* main.cpp:162-164 (positions) and main.cpp:100,109 (quaternions, D_IN = I_s (x) Dn_IN):       */
+/*   ivp(i, c) = Dn_IN(i) * x_base(c)      — rank-1, m x s, column-major                        */
+int sri_oracle_ivp(uint32_t m, uint32_t s, const double *Din, const double *x_base, double *ivp, size_t ld)
+{
+    if (!Din || !x_base || !ivp || ld < m) return SRI_EINVAL;
+    for (uint32_t c = 0; c < s; ++c)
+        for (uint32_t i = 0; i < m; ++i) ivp[i + c * ld] = Din[i] * x_base[c];
+    return SRI_OK;
+}
+
+/* THE apply — main.cpp:172  r_stack = Dn_NN_inv * (b_NN - ivp)  and the Kronecker form          */
+/* main.cpp:97 (I_s (x) Dn) * vec(X) == vec(Dn * X).                                            */
+/*   Y[r x M] = A[r x k] * X[k x M], all column-major, plain k-ascending multiply-then-add      */
+/*   (no FMA: the reference sets no -march flags, CMakeLists.txt:8-9).                          */
+/* Written in axpy order (k outer, i inner) so the compiler can vectorise over i; every         */
+/* Y(i,j) still receives its products in ascending k, i.e. the same rounding sequence as the    */
+/* textbook dot-product loop.                                                                   */
+int sri_oracle_apply(uint32_t r, uint32_t k, const double *A, size_t lda,
+                     const double *X, size_t ldx, double *Y, size_t ldy, size_t M)
+{
+    if (!A || !X || !Y || lda < r || ldx < k || ldy < r) return SRI_EINVAL;
+    for (size_t j = 0; j < M; ++j) {
+        double *restrict y = Y + j * ldy;
+        const double *restrict xj = X + j * ldx;
+        for (uint32_t i = 0; i < r; ++i) y[i] = 0.0;
+        for (uint32_t kk = 0; kk < k; ++kk) {
+            const double xv = xj[kk];
+            const double *restrict a = A + (size_t)kk * lda;
+            for (uint32_t i = 0; i < r; ++i) y[i] = y[i] + a[i] * xv;
+        }
+    }
+    return SRI_OK;
+}
+
+/* Textbook dot-product form of the same product, used by tests to show the axpy form above is  */
+/* bit-identical to it.                                                                         */
+int sri_oracle_apply_dot(uint32_t r, uint32_t k, const double *A, size_t lda,
+                         const double *X, size_t ldx, double *Y, size_t ldy, size_t M)
+{
+    if (!A || !X || !Y || lda < r || ldx < k || ldy < r) return SRI_EINVAL;
+    for (size_t j = 0; j < M; ++j)
+        for (uint32_t i = 0; i < r; ++i) {
+            double s = 0.0;
+            for (uint32_t kk = 0; kk < k; ++kk) s = s + A[i + (size_t)kk * lda] * X[kk + j * ldx];
+            Y[i + j * ldy] = s;
+        }
+    return SRI_OK;
+}
+
+/* main.cpp:172 in full, batched:  Y = Dnn_inv * (B - Din * x_base^T)                            */
+/*   B is m x M (M = s*rods), x_base is 1 x M (the base value of each column).                  */
+int sri_oracle_integrate(uint32_t m, const double *Dnn_inv, size_t lda, const double *Din,
+                         const double *B, size_t ldb, const double *x_base,
+                         double *Y, size_t ldy, size_t M)
+{
+    if (!Dnn_inv || !Din || !B || !x_base || !Y) return SRI_EINVAL;
+    double *rhs = (double *)malloc(sizeof(double) * (size_t)m);
+    if (!rhs) return SRI_ENOMEM;
+    for (size_t j = 0; j < M; ++j) {
+        for (uint32_t i = 0; i < m; ++i) rhs[i] = B[i + j * ldb] - Din[i] * x_base[j];
+        sri_oracle_apply(m, m, Dnn_inv, lda, rhs, m, Y + j * ldy, ldy, 1);
+    }
+    free(rhs);
+    return SRI_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rod model pieces needed to reproduce BASELINE config 1 (N=16, one rod) end to end.           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/utilities.h:49-67  Phi<na,ne>(X): strain basis, I_na (x) [P_0 .. P_{ne-1}](x),        */
+/*   x = (2X - (end+begin))/(end-begin) (h:54), P_l = boost::math::legendre_p(l, x) (h:59).     */
+/* Boost evaluates legendre_p by the recurrence P_{l+1} = ((2l+1) x P_l - l P_{l-1})/(l+1)      */
+/* starting from P_0 = 1, P_1 = x.  Returns only the ne basis values; the Kronecker product     */
+/* with I_na (h:63) is applied by the caller as K_a = sum_e P_e * qe[a*ne + e].                 */
+int sri_oracle_legendre_basis(double X, uint32_t ne, double *P)
+{
+    if (!P || ne < 1) return SRI_EINVAL;
+    const double t_begin = 0.0, t_end = 1.0;
+    const double x = (2 * X - (t_end + t_begin)) / (t_end - t_begin);
+    double p0 = 1.0, p1 = x;
+    P[0] = p0;
+    if (ne > 1) P[1] = p1;
+    for (uint32_t l = 1; l + 1 < ne; ++l) {
+        const double next = ((2 * l + 1) * x * p1 - l * p0) / (l + 1);
+        p0 = p1; p1 = next;
+        P[l + 1] = next;
+    }
+    return SRI_OK;
+}
+
+/* K = Phi<na,ne>(X) * qe    (main.cpp:33, 69).  na = 3 curvature components.                   */
+int sri_oracle_strain(double X, uint32_t na, uint32_t ne, const double *qe, double *K)
+{
+    double P[16];
+    if (ne > 16 || !qe || !K) return SRI_EINVAL;
+    sri_oracle_legendre_basis(X, ne, P);
+    for (uint32_t a = 0; a < na; ++a) {
+        /* row a of (I_na (x) P^T) times qe: zeros elsewhere contribute exact 0 terms */
+        double s = 0.0;
+        for (uint32_t e = 0; e < ne; ++e) s = s + P[e] * qe[a * ne + e];
+        K[a] = s;
+    }
+    return SRI_OK;
+}
+
+/* main.cpp:91-118 integrateQuaternions() with main.cpp:55-88 updateA():                        */
+/*   D_NN = I_4 (x) Dn_NN  (main.cpp:98);  A_NN = D_NN, then for every unknown node i the 16     */
+/*   entries (row*m+i, col*m+i) become D_NN(..) - 0.5*A(K_i)(row,col)  (main.cpp:78-84);         */
+/*   ivp = D_IN*q_init, q_init = (1,0,0,0) (main.cpp:106-109);                                   */
+/*   Q_stack = A_NN.inverse() * (b - ivp), b = 0  (main.cpp:111-113).                            */
+/* Q_stack (4m) is component-major: [w(0..m-1); x; y; z]  == column-major m x 4.                */
+int sri_oracle_integrate_quaternions(uint32_t n, const double *qe, uint32_t na, uint32_t ne,
+                                     const double *q_init, double *Q_stack)
+{
+    if (n < 2 || !qe || !Q_stack || na != 3) return SRI_EINVAL;
+    const uint32_t m = n - 1, s = 4, dim = s * m;
+    double *D = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *x = (double *)malloc(sizeof(double) * n);
+    double *Ann = (double *)calloc((size_t)dim * dim, sizeof(double));
+    double *Ainv = (double *)malloc(sizeof(double) * (size_t)dim * dim);
+    double *rhs = (double *)malloc(sizeof(double) * dim);
+    if (!D || !x || !Ann || !Ainv || !rhs) { free(D); free(x); free(Ann); free(Ainv); free(rhs); return SRI_ENOMEM; }
+    int rc = sri_oracle_dn(n, D, n);
+    sri_oracle_points(n, 1.0, x);
+    /* A_NN = D_NN = I_4 (x) Dn_NN */
+    for (uint32_t c = 0; c < s; ++c)
+        for (uint32_t j = 0; j < m; ++j)
+            for (uint32_t i = 0; i < m; ++i)
+                Ann[(c * m + i) + (size_t)(c * m + j) * dim] = D[i + (size_t)j * n];
+    /* updateA */
+    for (uint32_t i = 0; i < m; ++i) {
+        double K[3];
+        sri_oracle_strain(x[i], na, ne, qe, K);
+        const double Ak[4][4] = {
+            {0, -K[0], -K[1], -K[2]},
+            {K[0], 0, K[2], -K[1]},
+            {K[1], -K[2], 0, K[0]},
+            {K[2], K[1], -K[0], 0}};
+        for (uint32_t row = 0; row < s; ++row)
+            for (uint32_t col = 0; col < s; ++col) {
+                const size_t ri = row * m + i, ci = col * m + i;
+                /* D_NN(ri,ci) is Dn_NN(i,i) on the block diagonal and 0 off it */
+                const double dnn = (row == col) ? D[i + (size_t)i * n] : 0.0;
+                Ann[ri + ci * dim] = dnn - 0.5 * Ak[row][col];
+            }
+    }
+    /* ivp = (I_4 (x) Dn_IN) q_init ; rhs = 0 - ivp */
+    const double qi_default[4] = {1, 0, 0, 0};
+    const double *qi = q_init ? q_init : qi_default;
+    for (uint32_t c = 0; c < s; ++c)
+        for (uint32_t i = 0; i < m; ++i) {
+            double ivp = 0.0;
+            for (uint32_t cc = 0; cc < s; ++cc)
+                ivp = ivp + ((cc == c) ? D[i + (size_t)m * n] : 0.0) * qi[cc];
+            rhs[c * m + i] = 0.0 - ivp;
+        }
+    if (rc == SRI_OK) rc = sri_oracle_inverse(dim, Ann, dim, Ainv, dim);
+    if (rc == SRI_OK) rc = sri_oracle_apply_dot(dim, dim, Ainv, dim, rhs, dim, Q_stack, dim, 1);
+    free(D); free(x); free(Ann); free(Ainv); free(rhs);
+    return rc;
+}
+
+/* main.cpp:121-140 updatePositionb():  b.row(i) = (q_i.toRotationMatrix() * e1)^T               */
+/* Eigen's Quaternion::toRotationMatrix (no normalisation) first column:                         */
+/*   tx=2x ty=2y tz=2z ; twy=ty*w twz=tz*w ; txy=ty*x txz=tz*x ; tyy=ty*y tzz=tz*z               */
+/*   R(0,0)=1-(tyy+tzz) ; R(1,0)=txy+twz ; R(2,0)=txz-twy                                        */
+/* Q is column-major m x 4 (w,x,y,z), b is column-major m x 3.                                  */
+int sri_oracle_position_rhs(uint32_t m, const double *Q, size_t ldq, double *b, size_t ldb)
+{
+    if (!Q || !b || ldq < m || ldb < m) return SRI_EINVAL;
+    for (uint32_t i = 0; i < m; ++i) {
+        const double w = Q[i], x = Q[i + ldq], y = Q[i + 2 * ldq], z = Q[i + 3 * ldq];
+        const double ty = 2 * y, tz = 2 * z;
+        const double twy = ty * w, twz = tz * w;
+        const double txy = ty * x, txz = tz * x;
+        const double tyy = ty * y, tzz = tz * z;
+        b[i] = 1 - (tyy + tzz);
+        b[i + ldb] = txy + twz;
+        b[i + 2 * ldb] = txz - twy;
+    }
+    return SRI_OK;
+}
+
+/* main.cpp:145-176 integratePosition(): r_stack = Dn_NN^-1 * (b_NN - ivp), ivp = Dn_IN r_init^T */
+int sri_oracle_integrate_position(uint32_t n, const double *Q_stack, const double *r_init, double *r_stack)
+{
+    if (n < 2 || !Q_stack || !r_stack) return SRI_EINVAL;
+    const uint32_t m = n - 1;
+    double *Dinv = (double *)malloc(sizeof(double) * (size_t)m * m);
+    double *Din = (double *)malloc(sizeof(double) * m);
+    double *b = (double *)malloc(sizeof(double) * (size_t)m * 3);
+    double *ivp = (double *)malloc(sizeof(double) * (size_t)m * 3);
+    if (!Dinv || !Din || !b || !ivp) { free(Dinv); free(Din); free(b); free(ivp); return SRI_ENOMEM; }
+    const double r0[3] = {0, 0, 0};
+    const double *ri = r_init ? r_init : r0;
+    int rc = sri_oracle_integration(n, Dinv, m, Din);
+    sri_oracle_position_rhs(m, Q_stack, m, b, m);
+    sri_oracle_ivp(m, 3, Din, ri, ivp, m);
+    for (size_t t = 0; t < (size_t)m * 3; ++t) b[t] = b[t] - ivp[t];
+    if (rc == SRI_OK) rc = sri_oracle_apply_dot(m, m, Dinv, m, b, m, r_stack, m, 3);
+    free(Dinv); free(Din); free(b); free(ivp);
+    return rc;
+}

@@ -1,0 +1,80 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): plain-C restatement of the reference."""
+    import oracle as o
+
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def sri():
+    """The product package; builds libsri_hip.so with hipcc if it is not there yet."""
+    import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as pkg
+
+    if not os.path.exists(pkg.library_path()):
+        pkg.build_library()
+    pkg.load_library()
+    return pkg
+
+
+# ---- synthetic inputs: seed 0x5EED -------------------------------------------------
+SEED = 0x5EED
+
+
+def uniform_panel(rows: int, cols: int, seed: int = SEED) -> np.ndarray:
+    """X_ij ~ U[-1, 1), column-major rows x cols."""
+    rng = np.random.default_rng(seed)
+    return np.asfortranarray(rng.uniform(-1.0, 1.0, size=(cols, rows)).T)
+
+
+def rod_strain_panel(n: int, rods: int, seed: int = SEED, rows: int = None) -> np.ndarray:
+    """Smooth rod-strain-field panel, the cancellation-heavy case.
+
+    Per rod: qe ~ U[-2,2)^9, K(X_i) = Phi(X_i) qe at the Chebyshev nodes (utilities.h:49-67,
+    main.cpp:69) -> N x 3, 4th column cos(|K|).  Returns column-major rows x (4*rods), using the
+    first `rows` nodes (rows = n for D_N, n-1 for the integration operators).
+    """
+    rows = n if rows is None else rows
+    rng = np.random.default_rng(seed)
+    x = 0.5 * (1 + np.cos(np.pi * np.arange(n) / (n - 1)))
+    t = 2 * x - 1
+    P = np.stack([np.ones_like(t), t, 0.5 * (3 * t * t - 1)], axis=1)       # n x 3 Legendre basis
+    qe = rng.uniform(-2.0, 2.0, size=(rods, 3, 3))                          # rod, strain comp, mode
+    K = np.einsum("ne,rae->rna", P, qe)                                     # rod, node, comp
+    fourth = np.cos(np.linalg.norm(K, axis=2, keepdims=True))
+    panel = np.concatenate([K, fourth], axis=2)                             # rod, node, 4
+    out = panel[:, :rows, :].transpose(0, 2, 1).reshape(rods * 4, rows)     # (rod, comp) x node
+    return np.asfortranarray(out.T)
+
+
+def parity_metrics(A: np.ndarray, X: np.ndarray, Y: np.ndarray, Yref: np.ndarray):
+    """(Frobenius relative error, max backward error |E| / (|A||X|)) — BASELINE.md §4."""
+    E = Y - Yref
+    fro = np.linalg.norm(E) / max(np.linalg.norm(Yref), np.finfo(float).tiny)
+    scale = np.abs(A) @ np.abs(X)
+    scale[scale == 0] = np.finfo(float).tiny
+    back = float(np.max(np.abs(E) / scale))
+    return float(fro), back
+
+
+FRO_TOL = 1e-12                      # north_star: <= 1e-12 relative
+
+
+def backward_tol(n: int) -> float:   # 8 N 2^-53
+    return 8.0 * n * 2.0 ** -53

@@ -1,0 +1,244 @@
+"""GPU parity tests proper: the HIP apply (through the C ABI) against the CPU oracle.
+
+Bar (north_star): ||Y_gpu - Y_cpu||_F / ||Y_cpu||_F <= 1e-12 and
+max |E_ij| / (|A||X|)_ij <= 8 N 2^-53, GPU and oracle in the same process on the same host.
+"""
+import numpy as np
+import pytest
+
+from conftest import FRO_TOL, backward_tol, parity_metrics, rod_strain_panel, uniform_panel
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_panel(Xf):
+    import torch
+
+    # column-major rows x M  ==  C-contiguous (M, rows)
+    return torch.from_numpy(np.ascontiguousarray(Xf.T)).cuda()
+
+
+def _run(op, Xf):
+    import torch
+
+    Y = op.apply(_torch_panel(Xf))
+    torch.cuda.synchronize()
+    return np.asfortranarray(Y.cpu().numpy().T)
+
+
+def _operator_matrix(oracle, n, which):
+    if which == 0:
+        return oracle.dn(n)
+    Dinv, _ = oracle.integration(n)
+    if which == 1:
+        return Dinv
+    return oracle.blocks(oracle.dn(n))[0]
+
+
+@pytest.mark.parametrize("n,which,M", [
+    (16, 0, 4),          # BASELINE config 1 shape: one rod, 4 state columns
+    (16, 1, 3),          # main.cpp:172 as written: 15x15 . 15x3
+    (16, 0, 4096),
+    (64, 0, 16384),      # BASELINE config 2: N=64, 4096 rods
+    (64, 1, 1000),       # 63 rows: generic path, ragged M
+    (64, 2, 129),
+    (128, 0, 2048),      # mid geometry
+    (100, 0, 333),       # rows not a multiple of 16
+    (256, 0, 4096),      # config 3 shape, oracle-sized batch
+    (256, 0, 4099),      # ragged column tail on the DMA path
+    (256, 1, 1024),      # the integration apply at N=256: 255 rows
+    (512, 0, 512),
+    (1024, 0, 256),      # config 5 shape, oracle-sized batch
+    (1024, 1, 64),
+])
+@pytest.mark.parametrize("kind", ["uniform", "rod"])
+def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
+    A = _operator_matrix(oracle, n, which)
+    rows = A.shape[0]
+    if kind == "uniform":
+        X = uniform_panel(rows, M)
+    else:
+        X = rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M]
+        X = np.asfortranarray(X)
+    op = sri.SpectralApply(n, which)
+    assert op.rows == rows
+    Y = _run(op, X)
+    Yref = oracle.apply(A, X, threads=0)
+    fro, back = parity_metrics(A, X, Y, Yref)
+    assert back <= backward_tol(n), (back, op.last_kernel)
+    if fro > FRO_TOL:
+        # Cancellation-limited regime (only the smooth rod field at N=1024: ||D||_inf = 2.1e6 against
+        # |Y| ~ 1).  Two CORRECT fp64 summation orders differ there by 1.1e-12 in Frobenius norm
+        # (SURVEY.md §7 H4, Appendix B), so 1e-12 against the oracle is not attainable by any kernel
+        # that does not replay the oracle's exact k order.  Gate instead on: the backward error above,
+        # a hard cap of 1e-11, and the GPU result being no further from an 80-bit extended-precision
+        # product than the oracle itself is.
+        assert n >= 1024 and kind == "rod", (fro, n, kind)
+        assert fro <= 1e-11, fro
+        Yext = (A.astype(np.longdouble) @ X.astype(np.longdouble))
+        err_gpu = np.linalg.norm((Y - Yext).astype(np.float64))
+        err_cpu = np.linalg.norm((Yref - Yext).astype(np.float64))
+        assert err_gpu <= 1.25 * err_cpu, (err_gpu, err_cpu)
+    expect_dma = rows % 16 == 0
+    assert ("dma" in op.last_kernel) == expect_dma, op.last_kernel
+
+
+def test_mfma_layout_exact_integers(sri):
+    """Exact check of every index map (k order, row permutation, swizzle, tails) with small
+    integers: all products and sums are exact in fp64, so the result must be bit-identical.
+    Asymmetric data, as cdna_hip_programming.md §3 asks."""
+    rng = np.random.default_rng(7)
+    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (1024, 65)]:
+        A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
+        X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
+        op = sri.SpectralApply(rows, matrix=A)
+        Y = _run(op, X)
+        assert np.array_equal(Y, A @ X), (rows, M, op.last_kernel)
+
+
+def test_unaligned_and_strided_panels(sri, oracle):
+    """ld > rows and 8-byte-only alignment must fall back to the register path and stay correct."""
+    import ctypes as C
+    import torch
+
+    n, M = 64, 257
+    A = oracle.dn(n)
+    X = uniform_panel(n, M)
+    lib = sri.load_library()
+    op = sri.SpectralApply(n, 0)
+    for ld, shift in [(n, 1), (n + 1, 0), (n + 6, 0), (n + 3, 1)]:
+        bx = torch.zeros(ld * M + 2, dtype=torch.float64, device="cuda")
+        by = torch.full((ld * M + 2,), 777.0, dtype=torch.float64, device="cuda")
+        view = bx[shift:shift + ld * M].view(M, ld)
+        view[:, :n] = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+        rc = lib.sri_apply(op._h, bx.data_ptr() + 8 * shift, ld, by.data_ptr() + 8 * shift, ld, M,
+                           torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out = by[shift:shift + ld * M].view(M, ld).cpu().numpy()
+        Y = np.asfortranarray(out[:, :n].T)
+        fro, back = parity_metrics(A, X, Y, oracle.apply(A, X))
+        assert fro <= FRO_TOL and back <= backward_tol(n), (ld, shift, fro, back)
+        if ld > n:   # padding rows of Y must be untouched
+            assert np.all(out[:, n:] == 777.0), (ld, shift)
+        aligned = (ld % 2 == 0) and shift == 0
+        assert ("dma" in op.last_kernel) == aligned
+
+
+def test_empty_and_error_paths(sri):
+    import torch
+
+    op = sri.SpectralApply(64, 0)
+    X = torch.zeros((0, 64), dtype=torch.float64, device="cuda")
+    assert op.apply(X).shape == (0, 64)
+    with pytest.raises(ValueError):
+        op.apply(torch.zeros((4, 63), dtype=torch.float64, device="cuda"))
+    with pytest.raises(TypeError):
+        op.apply(torch.zeros((4, 64), dtype=torch.float32, device="cuda"))
+    with pytest.raises(sri.SriError):
+        sri.SpectralApply(1, 0)
+    with pytest.raises(sri.SriError):
+        sri.SpectralApply(64, 7)
+    lib = sri.load_library()
+    good = torch.zeros((4, 64), dtype=torch.float64, device="cuda")
+    assert lib.sri_apply(op._h, good.data_ptr(), 63, good.data_ptr(), 64, 4, None) == -1   # ld < rows
+    assert lib.sri_apply(None, good.data_ptr(), 64, good.data_ptr(), 64, 4, None) == -1
+    assert lib.sri_integrate(op._h, good.data_ptr(), 64, good.data_ptr(), good.data_ptr(), 64, 4, None) == -1  # not DNN_INV
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_integrate_matches_oracle(sri, oracle, n):
+    """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T)."""
+    import torch
+
+    M = 515
+    Dinv, Din = oracle.integration(n)
+    B = uniform_panel(n - 1, M, seed=11)
+    xb = np.random.default_rng(5).uniform(-1, 1, size=M)
+    op = sri.SpectralApply(n, sri.OP_DNN_INV)
+    Y = op.integrate(_torch_panel(B), torch.from_numpy(xb).cuda())
+    torch.cuda.synchronize()
+    Y = np.asfortranarray(Y.cpu().numpy().T)
+    Yref = oracle.integrate(Dinv, Din, B, xb)
+    rhs = B - np.outer(Din, xb)
+    fro, back = parity_metrics(Dinv, rhs, Y, Yref)
+    assert fro <= FRO_TOL, fro
+    # backward error is measured against |Dinv| (|B| + |Din||xb|): the epilogue form reassociates the rank-1 term
+    scale = np.abs(Dinv) @ (np.abs(B) + np.outer(np.abs(Din), np.abs(xb)))
+    assert np.max(np.abs(Y - Yref) / scale) <= backward_tol(n)
+
+
+def test_apply_host_roundtrip(sri, oracle):
+    n, M = 64, 300
+    A = oracle.dn(n)
+    X = uniform_panel(n, M)
+    op = sri.SpectralApply(n, 0)
+    Y = op.apply_host(X)
+    fro, back = parity_metrics(A, X, Y, oracle.apply(A, X))
+    assert fro <= FRO_TOL and back <= backward_tol(n)
+
+
+# ---- full BASELINE sizes: size-independent properties + sampled oracle columns ---------------------
+def _full_size_checks(sri, oracle, n, rods):
+    import torch
+
+    M = 4 * rods
+    op = sri.SpectralApply(n, 0)
+    g = torch.Generator(device="cuda").manual_seed(0x5EED)
+    X = torch.rand((M, n), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    Y = op.apply(X)
+    # (1) sampled columns against the oracle
+    idx = np.unique(np.concatenate([[0, 1, 63, 64, M - 65, M - 64, M - 1],
+                                    np.random.default_rng(3).integers(0, M, size=505)]))
+    A = oracle.dn(n)
+    ti = torch.from_numpy(idx).cuda()
+    Xs = np.asfortranarray(X[ti].cpu().numpy().T)
+    Ys = np.asfortranarray(Y[ti].cpu().numpy().T)
+    fro, back = parity_metrics(A, Xs, Ys, oracle.apply(A, Xs, threads=0))
+    assert fro <= FRO_TOL and back <= backward_tol(n), (fro, back)
+    # (2) linearity: A(aX1 + X2) == a A X1 + A X2 up to rounding of the combination
+    X2 = torch.rand((M, n), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    Y2 = op.apply(X2)
+    Y12 = op.apply(0.5 * X + X2)     # 0.5*X exact
+    lin = (Y12 - (0.5 * Y + Y2)).norm() / Y12.norm()
+    assert lin.item() <= 1e-12, lin.item()
+    # (3) every column checksum: sum_i Y_ij == (1^T A) X_j   (a checksum of checksums)
+    colsum = torch.from_numpy(A.sum(axis=0)).cuda()
+    lhs = Y.sum(dim=1)
+    rhs = X @ colsum
+    scale = (X.abs() @ torch.from_numpy(np.abs(A).sum(axis=0)).cuda())
+    assert ((lhs - rhs).abs() / scale).max().item() <= 64 * n * 2.0 ** -53
+    # (4) polynomials of degree <= 3 are differentiated exactly (to rounding)
+    x = torch.from_numpy(oracle.points(n)).cuda()
+    P = torch.stack([torch.ones_like(x), x, x * x, x ** 3]).contiguous()
+    dP = op.apply(P)
+    ref = torch.stack([torch.zeros_like(x), torch.ones_like(x), 2 * x, 3 * x * x])
+    assert (dP - ref).abs().max().item() <= 2.0 ** -53 * 2 * (n - 1) ** 2 * 64
+    del X, Y, X2, Y2, Y12
+    torch.cuda.empty_cache()
+
+
+def test_full_config2_n64(sri, oracle):
+    _full_size_checks(sri, oracle, 64, 4096)
+
+
+def test_full_config3_n256(sri, oracle):
+    _full_size_checks(sri, oracle, 256, 65536)
+
+
+def test_full_config5_n1024(sri, oracle):
+    _full_size_checks(sri, oracle, 1024, 8192)
+
+
+def test_differentiate_then_integrate_roundtrip(sri, oracle):
+    """Dn_NN^-1 (Dn_NN V) == V: the two operators of main.cpp:158-159 undo each other."""
+    import torch
+
+    n, M = 256, 16384
+    fwd = sri.SpectralApply(n, sri.OP_DNN)
+    inv = sri.SpectralApply(n, sri.OP_DNN_INV)
+    V = torch.from_numpy(np.ascontiguousarray(rod_strain_panel(n, M // 4, rows=n - 1).T)).cuda()
+    W = inv.apply(fwd.apply(V))
+    rel = (W - V).norm() / V.norm()
+    # cond_2(Dn_NN) = 5.2e4 at N=256 bounds the amplification of rounding
+    assert rel.item() <= 5.2e4 * 2.0 ** -53 * 64, rel.item()
