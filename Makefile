@@ -1,0 +1,26 @@
+# Top-level convenience targets (everything can also be built by `python -c "import __graft_entry__ as g; g.build()"`).
+PKG   := experimental_gpu_programming_for_a_spectral_numerical_integration_amd
+HIPCC ?= /opt/rocm/bin/hipcc
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -I$(PKG)/csrc
+
+all: lib oracle
+
+lib:
+	$(MAKE) -C $(PKG)/csrc
+
+oracle:
+	$(MAKE) -C oracle
+
+# measurement tooling (not product code); binaries land in build/ (git-ignored, travels with gpurun)
+tools: build/mfma_f64_probe build/apply_diag
+
+build/mfma_f64_probe: tools/mfma_f64_probe.hip
+	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -include algorithm $< -o $@
+
+build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Wno-pass-failed tools/apply_diag.hip $(PKG)/csrc/sri_host.cpp -o $@
+
+clean:
+	$(MAKE) -C $(PKG)/csrc clean; $(MAKE) -C oracle clean; rm -rf build
+
+.PHONY: all lib oracle tools clean

@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "sri_internal.h"
@@ -61,14 +62,18 @@ static thread_local int g_last_hip_error = 0;
 // ---------------------------------------------------------------------------------------------
 constexpr int BK = kChunkK;          // 16 k per stage
 constexpr int KPAIRS = BK / 8;       // 16-byte fragment reads per stage and tile
-constexpr int NSTAGE = 2;
 constexpr int X_ROW_BYTES = BK * 8;  // one column of the X stage: 128 B = 8 pieces of 16 B
+#ifndef SRI_SCHED_HINTS
+#define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
+#endif
 
-template <int WM_, int WN_, int TM_, int TN_>
+// WM x WN waves, each owning TM x TN MFMA tiles of 16x16; NSTAGE LDS ring slots.
+template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
 struct Geo {
-  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_;
   static constexpr int NW = WM * WN;
   static constexpr int THREADS = 64 * NW;
+  static constexpr int WAVES_PER_SIMD = (NW + 3) / 4 < 2 ? 2 : (NW + 3) / 4;   // launch-bounds hint
   static constexpr int BM = WM * TM * 16;
   static constexpr int BN = WN * TN * 16;
   static constexpr int A_BYTES = BM * BK * 8;
@@ -77,8 +82,13 @@ struct Geo {
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int A_DMA_PER_WAVE = A_BYTES / 1024 / NW;
   static constexpr int X_DMA_PER_WAVE = X_BYTES / 1024 / NW;
+  static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
+  static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
+  static constexpr int NSTORE = TM * TN * 2;                            // 16-byte Y stores per lane of a full tile
   static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
-  static_assert(THREADS == 256, "two 256-thread workgroups per CU is what the LDS/VGPR budget is sized for");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
+  static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
+  static_assert((AHEAD - 1) * DMA_PER_WAVE + NSTORE <= 63, "counted vmcnt must fit the 6-bit counter");
 };
 
 struct ApplyArgs {
@@ -91,6 +101,8 @@ struct ApplyArgs {
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
   uint32_t row_blocks;
+  uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
+  unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
 };
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
@@ -98,80 +110,152 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Diagnostic builds: keep a register value opaque/live without emitting an instruction.  (The "v"
+// constraint only exists for the device pass; the host pass parses kernel bodies too.)
+template <class T>
+__device__ __forceinline__ void keep_live(T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+}
+
+// Wait until all but the YOUNGER youngest vector-memory operations of this wave have completed
+// (vmcnt counts loads, LDS-DMA and stores together, in issue order) and its LDS writes are done,
+// then rendezvous.  __syncthreads() is not used in the kernel: its fence always drains vmcnt to 0,
+// which would also wait for the newest stages in flight and for the previous tile's Y stores.
+template <int YOUNGER>
+__device__ __forceinline__ void wait_stage_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNGER) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
-// The kernel.
+// The kernel: PERSISTENT.  gridDim.x workgroups (<= resident capacity of the chip) each walk
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The (tile, k chunk) pairs of a workgroup form ONE
+// stream of stages pushed through an NSTAGE-slot LDS ring with NSTAGE-1 stages in flight: the ring
+// keeps streaming across tile boundaries, and the Y stores of a finished tile drain behind the
+// next tile's MFMAs (the first AHEAD waits of a tile allow them to stay outstanding).
 //   DMA   : X by LDS-DMA (needs 16-byte aligned columns and rows % 16 == 0), Y by 16-byte stores.
 //           Otherwise X goes through registers with bounds checks and zero fill, Y by guarded
 //           8-byte stores: any rows / ld / M / alignment.
 //   RANK1 : epilogue subtracts w[row]*xb[col] (the initial-value term of main.cpp:162-164,172).
+//   STAMP : diagnostic only — lane 0 of each workgroup records shader-clock / real-time stamps.
+//   ABL   : diagnostic only (tools/apply_diag.hip) — ablation mask, results are WRONG when non-zero:
+//           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
+//           4 = no Y stores, 8 = read LDS fragments only in the first stage,
+//           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts.
 // ---------------------------------------------------------------------------------------------
-template <class G, bool DMA, bool RANK1>
-__global__ __launch_bounds__(G::THREADS, 2) void apply_kernel(const ApplyArgs p) {
+template <class G, bool DMA, bool RANK1, bool STAMP = false, int ABL = 0>
+__global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW;
+  constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
+  if constexpr (STAMP) {
+    st_t0 = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();
+  }
 
+  if constexpr ((ABL & 16) != 0) {
+    // one tile = nk stages x 2*TM*TN MFMAs x 64 cycles x waves per SIMD; s_sleep 127 ~ 8128 cycles
+    const unsigned steps = (blockIdx.x % 8) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 8 / 8128;
+    for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int c = lane & 15, g = lane >> 4;
 
-  const uint32_t rb = blockIdx.x % p.row_blocks;
-  const size_t ct = blockIdx.x / p.row_blocks;
-  const size_t col0 = ct * G::BN;
+  const uint32_t ntiles = p.row_blocks * p.col_tiles;
   const size_t last_col = p.m - 1;
+  const uint32_t first_tile = blockIdx.x;      // host guarantees gridDim.x <= ntiles
+  const uint32_t my_tiles = (ntiles - first_tile + gridDim.x - 1) / gridDim.x;
+  const uint32_t total_stages = my_tiles * p.nk;
 
-  // ---- per-lane constants of the X staging --------------------------------------------------
+  // ---- issue-side cursor: the (tile, chunk) whose stage is fetched next ------------------------
   // DMA: instruction i (= wid + it*NW) covers columns 8i..8i+7 of the tile; this lane writes
   // piece position (lane & 7) of column 8i + (lane >> 3), which must hold source piece
   // (lane & 7) ^ sigma(column).
   const char* xsrc[DMA ? G::X_DMA_PER_WAVE : 1];
-  if constexpr (DMA) {
+  const char* asrc;
+  uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
+  size_t col0_i = 0;
+  auto issue_setup = [&]() __attribute__((always_inline)) {
+    const uint32_t rb = tile_i / p.col_tiles;
+    col0_i = static_cast<size_t>(tile_i % p.col_tiles) * G::BN;
+    asrc = reinterpret_cast<const char*>(p.apack) + static_cast<size_t>(rb) * p.nk * G::A_BYTES + lane * 16;
+    if constexpr (DMA) {
 #pragma unroll
-    for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
-      const int cc = (wid + it * NW) * 8 + (lane >> 3);
-      const int piece = (lane & 7) ^ ((cc >> 1) & 7);
-      size_t col = col0 + cc;
-      col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
-      xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
+      for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
+        const int cc = (wid + it * NW) * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((cc >> 1) & 7);
+        size_t col = col0_i + cc;
+        col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
+        xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
+      }
     }
-  }
-  const char* asrc = reinterpret_cast<const char*>(p.apack) +
-                     static_cast<size_t>(rb) * p.nk * G::A_BYTES + lane * 16;
+  };
 
   // Register staging for the generic path: the X stage is BN*BK doubles, THREADS*XR of them.
   constexpr int XR = G::BN * BK / G::THREADS;
   double xreg[DMA ? 1 : XR];
 
-  auto stage_issue = [&](uint32_t kc, int buf) {
-    char* sA = smem + buf * G::STAGE_BYTES;
-    const char* gA = asrc + static_cast<size_t>(kc) * G::A_BYTES;
+  bool abl_first = true;   // ablation builds only
+  // Fetch the stage under the cursor into ring slot slot_i; advance the cursor.
+  auto stage_issue = [&]() __attribute__((always_inline)) {
+    char* sA = smem + slot_i * G::STAGE_BYTES;
+    const char* gA = asrc + static_cast<size_t>(kc_i) * G::A_BYTES;
+    if (!(ABL & 1) || abl_first) {
 #pragma unroll
-    for (int it = 0; it < G::A_DMA_PER_WAVE; ++it) {
-      const int i = wid + it * NW;
-      lds_dma16(gA + i * 1024, sA + i * 1024);
+      for (int it = 0; it < G::A_DMA_PER_WAVE; ++it) {
+        const int i = wid + it * NW;
+        lds_dma16(gA + i * 1024, sA + i * 1024);
+      }
     }
     if constexpr (DMA) {
       char* sX = sA + G::A_BYTES;
+      if (!(ABL & 2) || abl_first) {
 #pragma unroll
-      for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
-        const int i = wid + it * NW;
-        lds_dma16(xsrc[it] + static_cast<size_t>(kc) * X_ROW_BYTES, sX + i * 1024);
+        for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
+          const int i = wid + it * NW;
+          lds_dma16(xsrc[it] + static_cast<size_t>(kc_i) * X_ROW_BYTES, sX + i * 1024);
+        }
       }
+      if constexpr (ABL != 0) abl_first = false;
     } else {
 #pragma unroll
       for (int r = 0; r < XR; ++r) {
         const int idx = tid + r * G::THREADS;      // element of the stage, k fastest
         const int cc = idx / BK, k = idx % BK;
-        const size_t col = col0 + cc;
-        const uint32_t kk = kc * BK + k;
+        const size_t col = col0_i + cc;
+        const uint32_t kk = kc_i * BK + k;
         xreg[r] = (col < p.m && kk < p.rows) ? p.x[col * p.ldx + kk] : 0.0;
       }
     }
   };
-  auto stage_commit = [&](int buf) {   // generic path only: registers -> swizzled LDS image
+  // One 1-KiB LDS-DMA piece of the stage under the cursor (DMA builds): pieces 0..A_DMA_PER_WAVE-1 move
+  // the operator slab, the rest the X panel.  Lets the main loop drop the pieces between MFMA groups.
+  auto issue_piece = [&](int idx) __attribute__((always_inline)) {
+    char* sA = smem + slot_i * G::STAGE_BYTES;
+    if (idx < G::A_DMA_PER_WAVE) {
+      if (!(ABL & 1) || abl_first) {
+        const int i = wid + idx * NW;
+        lds_dma16(asrc + static_cast<size_t>(kc_i) * G::A_BYTES + i * 1024, sA + i * 1024);
+      }
+    } else {
+      if (!(ABL & 2) || abl_first) {
+        const int it = idx - G::A_DMA_PER_WAVE;
+        const int i = wid + it * NW;
+        lds_dma16(xsrc[DMA ? it : 0] + static_cast<size_t>(kc_i) * X_ROW_BYTES, sA + G::A_BYTES + i * 1024);
+      }
+      if constexpr (ABL != 0) { if (idx == G::DMA_PER_WAVE - 1) abl_first = false; }
+    }
+  };
+  // generic path only: registers -> swizzled LDS image of the slot just issued
+  auto stage_commit = [&](uint32_t slot) __attribute__((always_inline)) {
     if constexpr (!DMA) {
-      char* sX = smem + buf * G::STAGE_BYTES + G::A_BYTES;
+      char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
 #pragma unroll
       for (int r = 0; r < XR; ++r) {
         const int idx = tid + r * G::THREADS;
@@ -181,88 +265,249 @@ __global__ __launch_bounds__(G::THREADS, 2) void apply_kernel(const ApplyArgs p)
       }
     }
   };
+  auto cursor_advance = [&]() __attribute__((always_inline)) {
+    ++issued;
+    slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
+    if (++kc_i == p.nk) {
+      kc_i = 0;
+      tile_i += gridDim.x;
+      if (issued < total_stages) issue_setup();
+    }
+  };
 
-  // ---- accumulators --------------------------------------------------------------------------
+  // ---- accumulators and fragment registers -----------------------------------------------------
   d4 acc[TM][TN];
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
 
-  // fragment read addresses (bytes, relative to the stage base)
+  // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   const int sig = (c >> 1) & 7;
   const int x_off = G::A_BYTES + (wn * TN * 16 + c) * X_ROW_BYTES;
 
-  auto compute = [&](int buf) {
-    const char* base = smem + buf * G::STAGE_BYTES;
+  // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
+  // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).  With PIECES (steady state of the
+  // DMA build) the refill's LDS-DMA pieces are dropped one by one behind the first MFMA groups and pinned
+  // there: a piece costs the issuing wave ~60-180 cycles, a group of TN MFMAs keeps the pipe busy for
+  // TN*64, so the DMA issue disappears in the MFMA shadow instead of idling the pipe after the barrier.
+  d2 abl_a[(ABL & 8) ? TM : 1], abl_b[(ABL & 8) ? TN : 1];
+  bool abl_read = true;
+  auto compute = [&](uint32_t slot, auto pieces_tag) __attribute__((always_inline)) {
+    constexpr bool PIECES = decltype(pieces_tag)::value;
+    const char* base = smem + slot * G::STAGE_BYTES;
+    int piece = 0;
 #pragma unroll
     for (int j = 0; j < KPAIRS; ++j) {
       d2 a[TM], b[TN];
+      if (!(ABL & 8) || abl_read) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-        a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
-      const int xpiece = ((4 * j + g) ^ sig) * 16;
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
+        const int xpiece = ((4 * j + g) ^ sig) * 16;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+        for (int tn = 0; tn < TN; ++tn)
+          b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+        if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) abl_a[tm] = a[tm];
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) abl_b[tn] = b[tn];
+          abl_read = false;
+        }
+      } else if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) { a[tm] = abl_a[tm]; keep_live(a[tm]); }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) { b[tn] = abl_b[tn]; keep_live(b[tn]); }
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+          if constexpr (PIECES) {
+            if (piece < G::DMA_PER_WAVE) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_piece(piece++);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
     }
   };
 
-  // ---- main loop: 2-stage ring, one barrier per chunk ------------------------------------------
-  stage_issue(0, 0);
-  stage_commit(0);
-  for (uint32_t kc = 0; kc < p.nk; ++kc) {
-    const int buf = kc & 1;
-    __syncthreads();                       // chunk kc landed (drains the LDS-DMA), chunk kc-1 fully consumed
-    const bool more = kc + 1 < p.nk;
-    if (more) stage_issue(kc + 1, buf ^ 1);
-    compute(buf);
-    if (more) stage_commit(buf ^ 1);
+  // ---- Y stores of a finished tile (registers -> HBM, no LDS, no wait) --------------------------
+  // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
+  auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    const uint32_t rb_c = tile / p.col_tiles;
+    const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
+    const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
+    const size_t col_base = col0_c + wn * (TN * 16) + g;
+    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows);
+    if constexpr ((ABL & 4) != 0) {
+      // ablation: keep the accumulators live, store nothing
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
+      return false;
+    } else if (full) {
+      // every lane stores: exactly NSTORE dwordx4 stores per wave, which the counted waits rely on
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const size_t col = col_base + tn * 16 + r * 4;
+            double* yp = p.y + col * p.ldy + row_base + 32 * t;
+            double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
+            if constexpr (RANK1) {
+              const double xbv = p.xb[col];
+              v0 -= p.w[row_base + 32 * t] * xbv;
+              v1 -= p.w[row_base + 32 * t + 1] * xbv;
+            }
+            *reinterpret_cast<d2*>(yp) = d2{v0, v1};
+          }
+      return true;
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t col = col_base + tn * 16 + r * 4;
+          if (col >= p.m) continue;
+          double* ycol = p.y + col * p.ldy;
+          double xbv = 0.0;
+          if constexpr (RANK1) xbv = p.xb[col];
+#pragma unroll
+          for (int t = 0; t < TM / 2; ++t) {
+            const uint32_t row = row_base + 32 * t;
+            double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
+            if constexpr (RANK1) {
+              if (row < p.rows) v0 -= p.w[row] * xbv;
+              if (row + 1 < p.rows) v1 -= p.w[row + 1] * xbv;
+            }
+            if constexpr (DMA) {
+              if (row < p.rows) *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
+            } else {
+              if (row < p.rows) ycol[row] = v0;
+              if (row + 1 < p.rows) ycol[row + 1] = v1;
+            }
+          }
+        }
+      return false;
+    }
+  };
+
+  // ---- the stage stream ----------------------------------------------------------------------------
+  // Stage s lives in ring slot s % NSTAGE.  Body of stage s:
+  //     wait: stage s landed ; barrier      (so every wave has also finished reading stage s-1)
+  //     refill the slot of stage s-1 with stage s+AHEAD   } one scheduling region: the DMA pieces and the
+  //     fragment reads + MFMAs of stage s                  } LDS reads are spread between the MFMAs
+  //     [last chunk of a tile: Y stores, accumulators back to zero]
+  constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stages s+1..s+AHEAD-1 is younger
+  constexpr int W_BOUNDARY = W_STEADY + G::NSTORE;          // ... plus one full tile's stores
+  const bool counted_ok = p.nk >= static_cast<uint32_t>(NSTAGE);   // at most one tile end inside any wait window
+
+  issue_setup();
+  for (int i = 0; i < AHEAD; ++i) {
+    if (issued < total_stages) {
+      const uint32_t slot = slot_i;
+      stage_issue();
+      stage_commit(slot);
+      cursor_advance();
+    }
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  const uint32_t row_base = rb * G::BM + wm * (TM * 16) + 2 * g;
+  uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor
+  bool prev_full = false;                                  // the previous tile issued exactly NSTORE stores per wave
+
+  // REFILL = true: steady state, a new stage is fetched in every body (unconditionally, so that the DMA
+  // pieces share a basic block with the MFMAs and can be scheduled between them); false: stream tail.
+  auto stage_body = [&](uint32_t s, auto refill_tag) __attribute__((always_inline)) {
+    constexpr bool REFILL = decltype(refill_tag)::value;
+    // Ops of this wave younger than stage s's DMA: the DMA of the stages in flight behind it, plus the Y
+    // stores of a tile that finished during the last AHEAD bodies (they follow that body's refill in
+    // program order).  Both counts are exact only in the common cases; otherwise drain.
+    if (REFILL) {
+      if (!(ABL & 4) && tile_c != first_tile && kc_c < static_cast<uint32_t>(AHEAD)) {
+        if (prev_full && counted_ok) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<0>();
+      } else {
+        wait_stage_and_barrier<W_STEADY>();
+      }
+    } else {
+      wait_stage_and_barrier<0>();                         // tail of the stream: fewer stages in flight
+    }
+    if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
+
+    const uint32_t rslot = slot_i;
+    constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+    if constexpr (REFILL && !PIECES) stage_issue();
+    compute(slot_c, std::integral_constant<bool, PIECES>{});
+    if constexpr (false) {
+      // Scheduling recipe for this region (LLVM SchedGroupMask: MFMA 0x8, VMEM read 0x20, DS read 0x100):
+      // first the k-pair-0 fragments, then one LDS-DMA piece after every second MFMA (a piece costs the
+      // issuing wave ~60-180 cycles; two MFMAs keep the pipe busy for 128), the k-pair-1 fragments
+      // half-way through k pair 0, then the remaining MFMAs.
+      constexpr int HALF = TM * TN;                        // MFMAs of one k-step
+      constexpr int LEAD = 2 * G::DMA_PER_WAVE < HALF ? 2 * G::DMA_PER_WAVE : HALF;
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const size_t col = col0 + (wn * TN + tn) * 16 + c;
-    if (col >= p.m) continue;
-    double* ycol = p.y + col * p.ldy;
-    double xbv = 0.0;
-    if constexpr (RANK1) xbv = p.xb[col];
+      for (int i = 0; i < LEAD / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if constexpr (G::DMA_PER_WAVE > LEAD / 2) __builtin_amdgcn_sched_group_barrier(0x020, G::DMA_PER_WAVE - LEAD / 2, 0);
+      if constexpr (HALF > LEAD) __builtin_amdgcn_sched_group_barrier(0x008, HALF - LEAD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * HALF, 0);
+    }
+    if constexpr (REFILL) {
+      stage_commit(rslot);
+      cursor_advance();
+    }
+    slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+    if (++kc_c < p.nk) return;
+
+    if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
+    prev_full = store_tile(tile_c);
+    kc_c = 0;
+    tile_c += gridDim.x;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const uint32_t row = row_base + tm * 16 + q * 8;
-        double v0 = acc[tm][tn][2 * q], v1 = acc[tm][tn][2 * q + 1];
-        if constexpr (RANK1) {
-          if (row < p.rows) v0 -= p.w[row] * xbv;
-          if (row + 1 < p.rows) v1 -= p.w[row + 1] * xbv;
-        }
-        if constexpr (DMA) {
-          if (row < p.rows) *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
-        } else {
-          if (row < p.rows) ycol[row] = v0;
-          if (row + 1 < p.rows) ycol[row + 1] = v1;
-        }
-      }
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+  };
+
+  const uint32_t steady_end = total_stages > static_cast<uint32_t>(AHEAD) ? total_stages - AHEAD : 0;
+  uint32_t s = 0;
+  for (; s < steady_end; ++s) stage_body(s, std::true_type{});
+  for (; s < total_stages; ++s) stage_body(s, std::false_type{});
+
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      unsigned long long* o = p.stamps + static_cast<size_t>(blockIdx.x) * 8;
+      o[0] = st_t0; o[1] = st_t1; o[2] = st_t2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime();
+      o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+      o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Handle
 // ---------------------------------------------------------------------------------------------
-using GeoTall = Geo<4, 1, 4, 4>;   // BM 256 x BN 64 : rows > 128   (N = 256, 1024, ...)
-using GeoMid = Geo<2, 2, 4, 2>;    // BM 128 x BN 64 : 64 < rows <= 128
-using GeoFlat = Geo<1, 4, 4, 1>;   // BM  64 x BN 64 : rows <= 64   (N = 16, 64)
+using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...)
+using GeoMid = Geo<2, 2, 4, 2, 3>;    // BM 128 x BN  64, 4 waves,  72 KiB ring, 2 WG/CU : 64 < rows <= 128
+using GeoFlat = Geo<1, 4, 4, 1, 3>;   // BM  64 x BN  64, 4 waves,  48 KiB ring, 3 WG/CU : rows <= 64 (N = 16, 64)
 
 enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2 };
 
@@ -274,6 +519,7 @@ struct sri_apply_handle {
   int which = -1;
   int geo = 0;
   uint32_t bm = 0, nk = 0, row_blocks = 0;
+  int num_cus = 0;
   double* d_apack = nullptr;
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   const char* last_kernel = "none";
@@ -292,27 +538,35 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
         for (int j = 0; j < KPAIRS; ++j)
           for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 2; ++e, ++o) {
-              const uint32_t row = rb * G::BM + tile * 16 + row_of_slot(l & 15);
+              const uint32_t row = rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15);
               const uint32_t k = kc * BK + k_of(j, l >> 4, e);
               if (row < rows && k < rows) out[o] = A[row + static_cast<size_t>(k) * lda];
             }
 }
 
+// Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
+// than there are tiles.  The residency number is queried once per kernel variant and device.
 template <class G, bool DMA, bool RANK1>
-static int launch(const ApplyArgs& args, size_t col_tiles, hipStream_t stream) {
-  static bool attr_set[16] = {};   // per device
+static int launch(ApplyArgs args, size_t col_tiles, int num_cus, hipStream_t stream) {
+  static int blocks_per_cu[16] = {};   // per device; 0 = not queried yet
   int dev = 0;
   SRI_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_kernel<G, DMA, RANK1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set[dev] = true;
+  if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
+  const auto kern = &apply_kernel<G, DMA, RANK1>;
+  if (blocks_per_cu[dev] == 0) {
+    SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                G::LDS_BYTES));
+    int nb = 0;
+    SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
+    blocks_per_cu[dev] = nb < 1 ? 1 : nb;
   }
-  const size_t blocks = col_tiles * args.row_blocks;
-  if (blocks == 0) return SRI_OK;
-  if (blocks > 0x7fffffffull) return SRI_EUNSUPPORTED;
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1>), dim3(static_cast<unsigned>(blocks)), dim3(G::THREADS),
-                     G::LDS_BYTES, stream, args);
+  const size_t tiles = col_tiles * args.row_blocks;
+  if (tiles == 0) return SRI_OK;
+  if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
+  args.col_tiles = static_cast<uint32_t>(col_tiles);
+  const size_t resident = static_cast<size_t>(num_cus) * blocks_per_cu[dev];
+  const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -320,17 +574,18 @@ static int launch(const ApplyArgs& args, size_t col_tiles, hipStream_t stream) {
 template <class G>
 static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
-  if (dma && rank1) return launch<G, true, true>(args, col_tiles, stream);
-  if (dma) return launch<G, true, false>(args, col_tiles, stream);
-  if (rank1) return launch<G, false, true>(args, col_tiles, stream);
-  return launch<G, false, false>(args, col_tiles, stream);
+  const int cus = h->num_cus;
+  if (dma && rank1) return launch<G, true, true>(args, col_tiles, cus, stream);
+  if (dma) return launch<G, true, false>(args, col_tiles, cus, stream);
+  if (rank1) return launch<G, false, true>(args, col_tiles, cus, stream);
+  return launch<G, false, false>(args, col_tiles, cus, stream);
 }
 
 static const char* kernel_name(int geo, bool dma) {
   static const char* names[3][2] = {
       {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>"},
       {"sri_apply_mfma_f64<128x64,reg>", "sri_apply_mfma_f64<128x64,dma>"},
-      {"sri_apply_mfma_f64<256x64,reg>", "sri_apply_mfma_f64<256x64,dma>"}};
+      {"sri_apply_mfma_f64<256x128,reg>", "sri_apply_mfma_f64<256x128,dma>"}};
   return names[geo][dma ? 1 : 0];
 }
 
@@ -350,7 +605,7 @@ struct DeviceGuard {
   }
 };
 
-static int check_device(int device) {
+static int check_device(int device, int* num_cus = nullptr) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -362,6 +617,7 @@ static int check_device(int device) {
   hipDeviceProp_t prop;
   SRI_HIP(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SRI_ENODEVICE;   // gfx950-only code object
+  if (num_cus) *num_cus = prop.multiProcessorCount;
   return SRI_OK;
 }
 
@@ -369,7 +625,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
                               int which, int device) {
   if (out == nullptr || A == nullptr || rows < 1 || lda < rows) return SRI_EINVAL;
   *out = nullptr;
-  int rc = check_device(device);
+  int num_cus = 0;
+  int rc = check_device(device, &num_cus);
   if (rc != SRI_OK) return rc;
   DeviceGuard guard;
   rc = guard.enter(device);
@@ -378,6 +635,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   sri_apply_t* h = new (std::nothrow) sri_apply_handle();
   if (h == nullptr) return SRI_ENOMEM;
   h->device = device;
+  h->num_cus = num_cus;
   h->rows = rows;
   h->which = which;
   h->geo = rows <= 64 ? GEO_FLAT : (rows <= 128 ? GEO_MID : GEO_TALL);
@@ -436,6 +694,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.rows = h->rows;
   args.nk = h->nk;
   args.row_blocks = h->row_blocks;
+  args.col_tiles = 0;   // set by launch()
+  args.stamps = nullptr;
 
   const bool dma = (h->rows % 16 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) &&
                    (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (reinterpret_cast<uintptr_t>(dY) % 16 == 0);

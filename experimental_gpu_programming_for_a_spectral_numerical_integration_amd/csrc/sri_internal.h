@@ -19,15 +19,18 @@ int cheb_integration(uint32_t n, double* Dnn_inv, size_t ld, double* Din);
 int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double* out, size_t ld);
 
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------
-// One v_mfma_f64_16x16x4_f64 consumes a 16x4 slice of A.  Lane l feeds row-slot i = l & 15 and
-// k-slot g = l >> 4, and receives output rows (g + 4*reg), reg = 0..3, of column l & 15.
-// We permute the 16 rows of every tile so that the two registers (2q, 2q+1) of lane (c, g) are
-// the ADJACENT rows 8q + 2g and 8q + 2g + 1: each lane then stores 16 contiguous bytes and the
-// four g-lanes of a column cover one 64-byte segment of Y.
-//   slot i = g + 4*reg = g + 8q + 4e   <->   row offset 8q + 2g + e
+// One v_mfma_f64_16x16x4_f64 computes D[i][j] += sum_k P[i][k] Q[k][j] (i, j < 16, k < 4); lane l feeds
+// P[l & 15][l >> 4] and Q[l >> 4][l & 15] and receives D[(l >> 4) + 4*reg][l & 15], reg = 0..3.
+// The kernel feeds the X fragment as P and the operator fragment as Q, i.e. it accumulates the
+// TRANSPOSED tile: i = column of Y, j = row of Y.  The 16 consecutive lanes of a quarter-wave then
+// hold 16 different ROWS of one column, and by interleaving the rows of two vertically adjacent
+// tiles (tm = 2t, 2t+1) every lane owns two ADJACENT rows: a Y store is 16 bytes per lane and
+// 256 contiguous bytes (two full cache lines) per quarter-wave, which is how the memory pipeline
+// consumes a wave's store.
+//   row slot j of tile tm (tm counted inside the wave's 64-row block)  <->  row 32*(tm>>1) + 2*j + (tm&1)
 constexpr int kChunkK = 16;   // k extent of one pipeline stage (BK)
 
-inline constexpr int row_of_slot(int i) { return 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1); }
+inline constexpr int row_of_slot(int tm, int j) { return 32 * (tm >> 1) + 2 * j + (tm & 1); }
 // k index inside a chunk for lane k-slot g, k-pair j, element e of the 16-byte fragment read:
 inline constexpr int k_of(int j, int g, int e) { return 8 * j + 2 * g + e; }
 

@@ -71,6 +71,65 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, unsig
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// ---------------------------------------------------------------- 4. power-limited rate on RANDOM operands
+// 16 accumulators, 16 distinct random A and B operand registers per lane (permuted pairs, so no
+// memory traffic at all): what the MFMA pipe sustains once DVFS has settled on realistic data.
+// Reports TFLOP/s and the in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz.
+__global__ __launch_bounds__(256) void random_rate_kernel(const double* rnd, double* out, int iters,
+                                                          unsigned long long* cyc, int zero) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 + 16 distinct random operand registers per lane; MFMA i of an iteration uses (a[i], b[(5i+it)&15]):
+  // every MFMA sees an operand pair different from its predecessor's, as in a real GEMM stream.
+  double a[16], b[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a[i] = zero ? 0.0 : rnd[(t * 32 + i) & 0xFFFFF]; b[i] = zero ? 0.0 : rnd[(t * 32 + 16 + i) & 0xFFFFF]; }
+  d4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[(5 * i) & 15]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + 7) & 15]), "v"(b[(3 * i + 1) & 15]));
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[t] = s;
+  if (threadIdx.x == 0) { cyc[blockIdx.x * 2] = t1 - t0; cyc[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+static void run_random(const char* name, int blocks, int iters, int zero, int launches) {
+  const int threads = 256;
+  std::vector<double> h(1 << 20);
+  unsigned long long x = 88172645463325252ull;
+  for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+  double *rnd, *out; unsigned long long* cyc;
+  CK(hipMalloc(&rnd, sizeof(double) * h.size())); CK(hipMemcpy(rnd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+  CK(hipMalloc(&out, sizeof(double) * blocks * threads)); CK(hipMalloc(&cyc, sizeof(unsigned long long) * 2 * blocks));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float last = 0;
+  for (int l = 0; l < launches; ++l) {   // several back-to-back launches: let DVFS settle, report the last
+    CK(hipEventRecord(e0));
+    random_rate_kernel<<<blocks, threads>>>(rnd, out, iters, cyc, zero);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&last, e0, e1));
+  }
+  std::vector<unsigned long long> c(2 * blocks);
+  CK(hipMemcpy(c.data(), cyc, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+  std::vector<double> ghz;
+  for (int b = 0; b < blocks; ++b) ghz.push_back((double)c[2 * b] / (double)c[2 * b + 1] * 0.1);
+  std::sort(ghz.begin(), ghz.end());
+  double flop = (double)blocks * 4 * iters * 16.0 * 2048.0;
+  printf("%-40s %8.3f ms  %7.2f TFLOP/s  in-kernel clock median %.3f GHz  -> %.1f cyc/MFMA/SIMD\n", name, last,
+         flop / (last * 1e-3) / 1e12, ghz[ghz.size() / 2], (double)c[0] / (iters * 16.0) / (blocks / 256));
+  CK(hipFree(rnd)); CK(hipFree(out)); CK(hipFree(cyc));
+}
+
 template <int MODE, int NACC, int VF>
 static void run_rate(const char* name, int blocks, int threads, int iters) {
   double* out; unsigned long long* cyc;
@@ -144,5 +203,9 @@ int main() {
   run_rate<2, 16, 8>("mfma + 8 v_fma_f64 per mfma", 256, 256, IT);
   run_rate<2, 16, 16>("mfma + 16 v_fma_f64 per mfma", 256, 256, IT);
   run_rate<2, 16, 8>("mfma + 8 v_fma_f64, 2 waves/SIMD", 512, 256, IT);
+  // 5. power-limited: ~60 ms launches, 6 back to back
+  run_random("mfma f64 RANDOM operands, 1 wave/SIMD", 256, 130000, 0, 6);
+  run_random("mfma f64 RANDOM operands, 2 waves/SIMD", 512, 65000, 0, 6);
+  run_random("mfma f64 ZERO operands,   2 waves/SIMD", 512, 65000, 1, 6);
   return 0;
 }
