@@ -144,13 +144,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed clock ramp (same step as the measured one), then the W warmup steps of the contract
+    # untimed clock ramp (the apply alone — no collective, so ranks need not agree on its length),
+    # then the W warmup steps of the contract
     t_ramp = time.perf_counter()
-    ramp_steps = 0
     while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
         for _ in range(20):
-            step(ramp_steps)
-            ramp_steps += 1
+            op.apply(X, out=Y)
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# profile_bench.sh — rocprofv3 evidence for bench.py's roofline object (run on the GPU box via gpurun).
+#   pass 1: --kernel-trace --stats            -> average duration of the apply kernel
+#   pass 2: --pmc FETCH_SIZE                  -> HBM read bytes   (own pass: TCC has 4 counter slots, FETCH_SIZE takes 3)
+#   pass 3: --pmc WRITE_SIZE                  -> HBM write bytes
+#   pass 4: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -> MFMA utilisation
+# PMC passes never use --sys-trace / runtime traces (gpurun refuses that combination).
+set -e
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag
+rm -rf $out && mkdir -p $out
+ARGS="bench.py --steps 200 --warmup 20 --ramp-ms 800 --cpu-seconds 0 --no-verify"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $ARGS > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python $ARGS > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python $ARGS > $out/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/sq -- python $ARGS > $out/sq.log 2>&1 || true
+python tools/summarize_profile.py $out $tag
