@@ -47,6 +47,7 @@ C_ABI = {
     "sri_apply": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp]),
     "sri_integrate": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
+    "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
     "sri_apply_destroy": (_int, [_vp]),
     "sri_apply_last_kernel": (C.c_char_p, [_vp]),
     "sri_strerror": (C.c_char_p, [_int]),

@@ -770,26 +770,43 @@ int sri_integrate(sri_apply_t* h, const double* dB, size_t ldb, const double* d_
   return sri::run(h, dB, ldb, dY, ldy, M, d_x_base, static_cast<hipStream_t>(hip_stream));
 }
 
-int sri_apply_host(sri_apply_t* h, const double* X, size_t ldx, double* Y, size_t ldy, size_t M) {
+static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x_base, double* Y, size_t ldy, size_t M) {
   if (h == nullptr || (M > 0 && (X == nullptr || Y == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
   if (M == 0) return SRI_OK;
   sri::DeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  using sri::g_last_hip_error;
   const size_t rows = h->rows;
   const size_t ldd = (rows + 1) & ~static_cast<size_t>(1);   // even leading dimension: DMA path when rows % 16 == 0
-  double *dX = nullptr, *dY = nullptr;
-  if (hipMalloc(&dX, ldd * M * sizeof(double)) != hipSuccess) return SRI_ENOMEM;
-  if (hipMalloc(&dY, ldd * M * sizeof(double)) != hipSuccess) { (void)hipFree(dX); return SRI_ENOMEM; }
-  auto done = [&](int code) { (void)hipFree(dX); (void)hipFree(dY); return code; };
+  double *dX = nullptr, *dY = nullptr, *dB = nullptr;
+  auto done = [&](int code) {
+    if (dX) (void)hipFree(dX);
+    if (dY) (void)hipFree(dY);
+    if (dB) (void)hipFree(dB);
+    return code;
+  };
+  if (hipMalloc(&dX, ldd * M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
+  if (hipMalloc(&dY, ldd * M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
+  if (x_base != nullptr) {
+    if (hipMalloc(&dB, M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
+    if (hipMemcpy(dB, x_base, M * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(SRI_EHIP);
+  }
   if (hipMemcpy2D(dX, ldd * sizeof(double), X, ldx * sizeof(double), rows * sizeof(double), M, hipMemcpyHostToDevice) != hipSuccess)
     return done(SRI_EHIP);
-  rc = sri::run(h, dX, ldd, dY, ldd, M, nullptr, nullptr);
+  rc = sri::run(h, dX, ldd, dY, ldd, M, dB, nullptr);
   if (rc != SRI_OK) return done(rc);
   if (hipMemcpy2D(Y, ldy * sizeof(double), dY, ldd * sizeof(double), rows * sizeof(double), M, hipMemcpyDeviceToHost) != hipSuccess)
     return done(SRI_EHIP);
   return done(SRI_OK);
+}
+
+int sri_apply_host(sri_apply_t* h, const double* X, size_t ldx, double* Y, size_t ldy, size_t M) {
+  return run_host(h, X, ldx, nullptr, Y, ldy, M);
+}
+
+int sri_integrate_host(sri_apply_t* h, const double* B, size_t ldb, const double* x_base, double* Y, size_t ldy, size_t M) {
+  if (h == nullptr || h->which != SRI_OP_DNN_INV || x_base == nullptr) return SRI_EINVAL;
+  return run_host(h, B, ldb, x_base, Y, ldy, M);
 }
 
 int sri_apply_destroy(sri_apply_t* h) {

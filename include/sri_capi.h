@@ -116,6 +116,10 @@ int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_
  * copies Y back, synchronises.  (PCIe-inclusive; never what bench.py times.) */
 int sri_apply_host(sri_apply_t *h, const double *X, size_t ldx, double *Y, size_t ldy, size_t M);
 
+/* Host-buffer form of sri_integrate (x_base: M host doubles). */
+int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double *x_base,
+                       double *Y, size_t ldy, size_t M);
+
 int sri_apply_destroy(sri_apply_t *h);
 
 /* ---------------------------------------------------------------------------------------- */
