@@ -289,57 +289,53 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int x_off = G::A_BYTES + (wn * TN * 16 + c) * X_ROW_BYTES;
 
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
-  // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).  With PIECES (steady state of the
-  // DMA build) the refill's LDS-DMA pieces are dropped one by one behind the first MFMA groups and pinned
-  // there: a piece costs the issuing wave ~60-180 cycles, a group of TN MFMAs keeps the pipe busy for
-  // TN*64, so the DMA issue disappears in the MFMA shadow instead of idling the pipe after the barrier.
-  d2 abl_a[(ABL & 8) ? TM : 1], abl_b[(ABL & 8) ? TN : 1];
+  // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
+  // "groups" (k-step e, row tile tm) of TN MFMAs each.  With PIECES (steady state of the DMA build) one
+  // LDS-DMA piece of the refill is dropped behind each group and pinned there: a piece costs the issuing
+  // wave ~60-180 cycles, a group keeps the pipe busy for TN*64, so the DMA issue disappears in the MFMA
+  // shadow instead of idling the pipe after the barrier.
+  constexpr int GROUPS = 2 * TM;
   bool abl_read = true;
-  auto compute = [&](uint32_t slot, auto pieces_tag) __attribute__((always_inline)) {
-    constexpr bool PIECES = decltype(pieces_tag)::value;
+  auto read_pair = [&](uint32_t slot, int j, d2 (&a)[TM], d2 (&b)[TN]) __attribute__((always_inline)) {
+    if ((ABL & 8) && !abl_read) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) keep_live(a[tm]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) keep_live(b[tn]);
+      return;
+    }
     const char* base = smem + slot * G::STAGE_BYTES;
-    int piece = 0;
 #pragma unroll
-    for (int j = 0; j < KPAIRS; ++j) {
-      d2 a[TM], b[TN];
-      if (!(ABL & 8) || abl_read) {
+    for (int tm = 0; tm < TM; ++tm)
+      a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
+    const int xpiece = ((4 * j + g) ^ sig) * 16;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
-        const int xpiece = ((4 * j + g) ^ sig) * 16;
+    for (int tn = 0; tn < TN; ++tn)
+      b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+  };
+  // groups [G0, G1) of the k pair held in (a, b); `piece` counts the DMA pieces issued so far in this body
+  auto mfma_groups = [&](const d2 (&a)[TM], const d2 (&b)[TN], auto g0_tag, auto g1_tag, int& piece, auto pieces_tag)
+                         __attribute__((always_inline)) {
+    constexpr int G0 = decltype(g0_tag)::value, G1 = decltype(g1_tag)::value;
+    constexpr bool PIECES = decltype(pieces_tag)::value;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
-        if constexpr ((ABL & 8) != 0) {
+    for (int gi = G0; gi < G1; ++gi) {
+      const int e = gi / TM, tm = gi % TM;
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm) abl_a[tm] = a[tm];
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) abl_b[tn] = b[tn];
-          abl_read = false;
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+      if constexpr (PIECES) {
+        if (piece < G::DMA_PER_WAVE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(piece++);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      } else if constexpr ((ABL & 8) != 0) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) { a[tm] = abl_a[tm]; keep_live(a[tm]); }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) { b[tn] = abl_b[tn]; keep_live(b[tn]); }
       }
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
-          if constexpr (PIECES) {
-            if (piece < G::DMA_PER_WAVE) {
-              __builtin_amdgcn_sched_barrier(0);
-              issue_piece(piece++);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
     }
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using IG = std::integral_constant<int, GROUPS>;
 
   // ---- Y stores of a finished tile (registers -> HBM, no LDS, no wait) --------------------------
   // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
@@ -406,14 +402,21 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   };
 
   // ---- the stage stream ----------------------------------------------------------------------------
-  // Stage s lives in ring slot s % NSTAGE.  Body of stage s:
-  //     wait: stage s landed ; barrier      (so every wave has also finished reading stage s-1)
-  //     refill the slot of stage s-1 with stage s+AHEAD   } one scheduling region: the DMA pieces and the
-  //     fragment reads + MFMAs of stage s                  } LDS reads are spread between the MFMAs
-  //     [last chunk of a tile: Y stores, accumulators back to zero]
-  constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stages s+1..s+AHEAD-1 is younger
+  // Stage s lives in ring slot s % NSTAGE; wait(s) + barrier(s) = "stage s has landed for every wave, and
+  // every wave has finished READING stage s-1", after which the slot of stage s-1 is refilled with stage
+  // s+AHEAD.  The two wave groups of a workgroup run the same stream against the same barriers but
+  // SHIFTED by most of a k pair:
+  //   early (waves 0..NW/2-1):  barrier(s) | pair (s,0) | pair (s,1) | [tile end: Y stores]
+  //   late  (waves NW/2..NW-1): reads (s-1,1), first group | barrier(s) | rest of (s-1,1) | [stores] | pair (s,0)
+  // Right after a barrier the late waves still own MFMAs whose operands are in registers, which covers the
+  // early waves' LDS-read latency; each group's Y stores (limited to ~64 B/clk per CU) are issued while the
+  // other group is in the middle of its MFMAs; and the DMA pieces of both groups sit behind MFMA groups.
+  // LDS hazards are those of the unshifted stream because every read of slot s-1 still precedes barrier(s).
+  constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
   constexpr int W_BOUNDARY = W_STEADY + G::NSTORE;          // ... plus one full tile's stores
-  const bool counted_ok = p.nk >= static_cast<uint32_t>(NSTAGE);   // at most one tile end inside any wait window
+  static_assert(AHEAD == 2, "the wait counts assume two stages in flight");
+  constexpr bool STAGGER = (NW >= 8) && (SRI_SCHED_HINTS != 0);
+  const bool late = STAGGER && wid >= NW / 2;
 
   issue_setup();
   for (int i = 0; i < AHEAD; ++i) {
@@ -425,70 +428,135 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
   }
 
-  uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor
-  bool prev_full = false;                                  // the previous tile issued exactly NSTORE stores per wave
+  uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor (stage whose k pair 0 comes next)
+  uint32_t since_store = 99;                               // waits since a FULL tile's NSTORE stores were issued
+  d2 fa[TM], fb[TN];
 
-  // REFILL = true: steady state, a new stage is fetched in every body (unconditionally, so that the DMA
-  // pieces share a basic block with the MFMAs and can be scheduled between them); false: stream tail.
-  auto stage_body = [&](uint32_t s, auto refill_tag) __attribute__((always_inline)) {
-    constexpr bool REFILL = decltype(refill_tag)::value;
-    // Ops of this wave younger than stage s's DMA: the DMA of the stages in flight behind it, plus the Y
-    // stores of a tile that finished during the last AHEAD bodies (they follow that body's refill in
-    // program order).  Both counts are exact only in the common cases; otherwise drain.
-    if (REFILL) {
-      if (!(ABL & 4) && tile_c != first_tile && kc_c < static_cast<uint32_t>(AHEAD)) {
-        if (prev_full && counted_ok) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<0>();
-      } else {
-        wait_stage_and_barrier<W_STEADY>();
-      }
+  // wait(s) + barrier(s).  Ops of this wave younger than stage s's DMA: the DMA of stage s+1, plus a full
+  // tile's stores if they were issued after stage s's DMA, i.e. within the last two bodies.
+  auto wait_stage = [&](auto refill_tag) __attribute__((always_inline)) {
+    if (decltype(refill_tag)::value) {
+      if (since_store < 2) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<W_STEADY>();
     } else {
       wait_stage_and_barrier<0>();                         // tail of the stream: fewer stages in flight
     }
+    if (since_store < 99) ++since_store;
     if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
-
-    const uint32_t rslot = slot_i;
-    constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
-    if constexpr (REFILL && !PIECES) stage_issue();
-    compute(slot_c, std::integral_constant<bool, PIECES>{});
-    if constexpr (false) {
-      // Scheduling recipe for this region (LLVM SchedGroupMask: MFMA 0x8, VMEM read 0x20, DS read 0x100):
-      // first the k-pair-0 fragments, then one LDS-DMA piece after every second MFMA (a piece costs the
-      // issuing wave ~60-180 cycles; two MFMAs keep the pipe busy for 128), the k-pair-1 fragments
-      // half-way through k pair 0, then the remaining MFMAs.
-      constexpr int HALF = TM * TN;                        // MFMAs of one k-step
-      constexpr int LEAD = 2 * G::DMA_PER_WAVE < HALF ? 2 * G::DMA_PER_WAVE : HALF;
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-      for (int i = 0; i < LEAD / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      if constexpr (G::DMA_PER_WAVE > LEAD / 2) __builtin_amdgcn_sched_group_barrier(0x020, G::DMA_PER_WAVE - LEAD / 2, 0);
-      if constexpr (HALF > LEAD) __builtin_amdgcn_sched_group_barrier(0x008, HALF - LEAD, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * HALF, 0);
-    }
-    if constexpr (REFILL) {
-      stage_commit(rslot);
-      cursor_advance();
-    }
-    slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
-    if (++kc_c < p.nk) return;
-
+  };
+  // Y stores of `tile` + accumulators back to zero
+  auto finish_tile = [&](uint32_t tile) __attribute__((always_inline)) {
     if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
-    prev_full = store_tile(tile_c);
-    kc_c = 0;
-    tile_c += gridDim.x;
+    if (store_tile(tile)) {
+      since_store = 0;
+    } else {
+      if constexpr ((ABL & 4) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // edge tile: unknown store count, drain
+      since_store = 99;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
   };
+  auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
+    slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+    if (++kc_c < p.nk) return false;
+    kc_c = 0;
+    tile_c += gridDim.x;
+    return true;
+  };
 
   const uint32_t steady_end = total_stages > static_cast<uint32_t>(AHEAD) ? total_stages - AHEAD : 0;
-  uint32_t s = 0;
-  for (; s < steady_end; ++s) stage_body(s, std::true_type{});
-  for (; s < total_stages; ++s) stage_body(s, std::false_type{});
+
+  if (!late) {
+    // ---------------- early group (or the whole workgroup when STAGGER is off) ----------------------
+    auto body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      wait_stage(refill_tag);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      int piece = 0;
+      read_pair(slot_c, 0, fa, fb);
+      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
+      read_pair(slot_c, 1, fa, fb);
+      if constexpr ((ABL & 8) != 0) abl_read = false;
+      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
+      if constexpr (PIECES) {
+#pragma unroll
+        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
+      }
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+      const uint32_t done_tile = tile_c;
+      if (advance_compute()) finish_tile(done_tile);
+    };
+    uint32_t s = 0;
+    for (; s < steady_end; ++s) body(std::true_type{});
+    for (; s < total_stages; ++s) body(std::false_type{});
+  } else {
+    // ---------------- late group: shifted by a k pair minus one MFMA group --------------------------
+    // body(s), s >= 1:  reads (s-1, pair 1), group 0 | wait(s), barrier(s) | groups 1.. of (s-1, 1) with the
+    // DMA pieces | [stage s-1 closed a tile: stores] | pair (s, 0)
+    auto first_body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      wait_stage(refill_tag);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      int piece = 0;
+      read_pair(slot_c, 0, fa, fb);
+      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
+      if constexpr (PIECES) {
+#pragma unroll
+        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
+      }
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+    };
+    auto body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      int piece = 0;
+      read_pair(slot_c, 1, fa, fb);                        // slot_c still names stage s-1
+      if constexpr ((ABL & 8) != 0) abl_read = false;
+      mfma_groups(fa, fb, I0{}, I1{}, piece, std::false_type{});
+      wait_stage(refill_tag);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      mfma_groups(fa, fb, I1{}, IG{}, piece, PT{});
+      if constexpr (PIECES) {
+#pragma unroll
+        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
+      }
+      const uint32_t done_tile = tile_c;
+      if (advance_compute()) finish_tile(done_tile);       // now slot_c names stage s
+      read_pair(slot_c, 0, fa, fb);
+      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+    };
+    uint32_t s = 0;
+    if (steady_end > 0) first_body(std::true_type{}); else first_body(std::false_type{});
+    for (s = 1; s < steady_end; ++s) body(std::true_type{});
+    for (; s < total_stages; ++s) body(std::false_type{});
+    // second k pair of the last stage
+    {
+      int piece = 0;
+      read_pair(slot_c, 1, fa, fb);
+      mfma_groups(fa, fb, I0{}, IG{}, piece, std::false_type{});
+      const uint32_t done_tile = tile_c;
+      if (advance_compute()) finish_tile(done_tile);
+    }
+  }
 
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
