@@ -430,7 +430,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor (stage whose k pair 0 comes next)
   uint32_t since_store = 99;                               // waits since a FULL tile's NSTORE stores were issued
-  d2 fa[TM], fb[TN];
+  // Two fragment register sets: (pa, pb) holds k pair 0 of a stage, (qa, qb) k pair 1.  Every fragment read
+  // is issued at least two MFMA groups before its first use, except the early group's read right after a
+  // barrier, which the late group's MFMAs cover.
+  d2 pa[TM], pb[TN], qa[TM], qb[TN];
+  using I2 = std::integral_constant<int, 2>;
+  using IL = std::integral_constant<int, GROUPS - 2>;
 
   // wait(s) + barrier(s).  Ops of this wave younger than stage s's DMA: the DMA of stage s+1, plus a full
   // tile's stores if they were issued after stage s's DMA, i.e. within the last two bodies.
@@ -464,6 +469,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     tile_c += gridDim.x;
     return true;
   };
+  auto flush_pieces = [&](int& piece, auto pieces_tag) __attribute__((always_inline)) {
+    if constexpr (decltype(pieces_tag)::value) {
+#pragma unroll
+      for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
+    }
+  };
 
   const uint32_t steady_end = total_stages > static_cast<uint32_t>(AHEAD) ? total_stages - AHEAD : 0;
 
@@ -477,15 +488,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
-      read_pair(slot_c, 0, fa, fb);
-      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
-      read_pair(slot_c, 1, fa, fb);
+      read_pair(slot_c, 0, pa, pb);
+      mfma_groups(pa, pb, I0{}, I2{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);
       if constexpr ((ABL & 8) != 0) abl_read = false;
-      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
-      if constexpr (PIECES) {
-#pragma unroll
-        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
-      }
+      mfma_groups(pa, pb, I2{}, IG{}, piece, PT{});
+      mfma_groups(qa, qb, I0{}, IG{}, piece, PT{});
+      flush_pieces(piece, PT{});
       if constexpr (REFILL) {
         stage_commit(rslot);
         cursor_advance();
@@ -498,8 +507,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     for (; s < total_stages; ++s) body(std::false_type{});
   } else {
     // ---------------- late group: shifted by a k pair minus one MFMA group --------------------------
-    // body(s), s >= 1:  reads (s-1, pair 1), group 0 | wait(s), barrier(s) | groups 1.. of (s-1, 1) with the
-    // DMA pieces | [stage s-1 closed a tile: stores] | pair (s, 0)
+    // body(s), s >= 1 (entered with k pair 1 of stage s-1 already in (qa, qb)):
+    //   group 0 of (s-1, 1) | wait(s), barrier(s) | read (s, 0) | groups 1.. of (s-1, 1) with the DMA pieces |
+    //   [stage s-1 closed a tile: stores] | groups of (s, 0), reading (s, 1) two groups before the end
     auto first_body = [&](auto refill_tag) __attribute__((always_inline)) {
       constexpr bool REFILL = decltype(refill_tag)::value;
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
@@ -508,12 +518,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
-      read_pair(slot_c, 0, fa, fb);
-      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
-      if constexpr (PIECES) {
-#pragma unroll
-        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
-      }
+      read_pair(slot_c, 0, pa, pb);
+      mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);
+      if constexpr ((ABL & 8) != 0) abl_read = false;
+      mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      flush_pieces(piece, PT{});
       if constexpr (REFILL) {
         stage_commit(rslot);
         cursor_advance();
@@ -524,21 +534,19 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
       int piece = 0;
-      read_pair(slot_c, 1, fa, fb);                        // slot_c still names stage s-1
-      if constexpr ((ABL & 8) != 0) abl_read = false;
-      mfma_groups(fa, fb, I0{}, I1{}, piece, std::false_type{});
+      mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
       wait_stage(refill_tag);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
-      mfma_groups(fa, fb, I1{}, IG{}, piece, PT{});
-      if constexpr (PIECES) {
-#pragma unroll
-        for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
-      }
+      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+      read_pair(next_slot, 0, pa, pb);                               // (s, 0): landed, consumed 7 groups later
+      mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
+      flush_pieces(piece, PT{});
       const uint32_t done_tile = tile_c;
-      if (advance_compute()) finish_tile(done_tile);       // now slot_c names stage s
-      read_pair(slot_c, 0, fa, fb);
-      mfma_groups(fa, fb, I0{}, IG{}, piece, PT{});
+      if (advance_compute()) finish_tile(done_tile);                 // now slot_c names stage s
+      mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);                                  // (s, 1): used at the top of the next body
+      mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
       if constexpr (REFILL) {
         stage_commit(rslot);
         cursor_advance();
@@ -551,8 +559,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     // second k pair of the last stage
     {
       int piece = 0;
-      read_pair(slot_c, 1, fa, fb);
-      mfma_groups(fa, fb, I0{}, IG{}, piece, std::false_type{});
+      mfma_groups(qa, qb, I0{}, IG{}, piece, std::false_type{});
       const uint32_t done_tile = tile_c;
       if (advance_compute()) finish_tile(done_tile);
     }
