@@ -7,10 +7,12 @@
 
 A "step" is one pass of the hot path over one batch of synthetic state panels already resident in
 HBM: Y = D_N . X with N = 256 nodes and 65 536 rods (x 4 state columns) PER GPU — BASELINE.json
-configs[2] at N=1, configs[3] at 8 GPUs (weak scaling on the batch axis).  For N > 1 every step
-also all-gathers the integrated tip state of every rod over RCCL/xGMI, overlapped with the next
-step's apply on a side stream (north_star: "all-gather ... only to reassemble the final integrated
-state"); the apply itself needs no collective.
+configs[2] at N=1, configs[3] at 8 GPUs (weak scaling on the batch axis).  The apply needs no
+collective (rods are independent, the operator is replicated).  For N > 1 the job ends with ONE RCCL
+all-gather over xGMI of the integrated tip state of every rod (north_star: "all-gather ... only to
+reassemble the final integrated state"), inside the timed region; every apply emits its tip state from
+the kernel epilogue at no extra traffic.  `--gather tip` gathers after every step instead (overlapped on
+a side stream); the cost of one tip gather and of one full-panel gather are reported separately.
 
 Rank 0 prints ONE JSON line.  `roofline` is computed from ALGORITHMIC flops (8 N^2 per rod-state,
 SURVEY.md §8d) and the kernel's mean launch duration measured here with HIP events on the launch
@@ -47,7 +49,13 @@ def parse():
     ap.add_argument("--n", type=int, default=256, help="Chebyshev nodes N")
     ap.add_argument("--rods", type=int, default=65536, help="rods per GPU (4 state columns each)")
     ap.add_argument("--operator", choices=["dn", "dnn_inv"], default="dn")
-    ap.add_argument("--gather", choices=["tip", "full", "none"], default="tip", help="exchange step when N > 1")
+    ap.add_argument("--gather", choices=["final", "tip", "full", "none"], default="final",
+                    help="exchange when N > 1: final = ONE all-gather of the integrated tip state after the K steps, "
+                         "inside the timed region (default); tip = one per step, overlapped on a side stream; "
+                         "full = whole output panel per step; none")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="CUs left free for an overlapped RCCL kernel (0 = none: with 8 tiles per workgroup a smaller "
+                         "grid costs a whole extra round of tiles, measured +12%%)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
@@ -81,6 +89,11 @@ def cpu_baseline(n: int, budget_s: float):
 
 def main():
     args = parse()
+    # Libraries (RCCL's version banner, ...) write to stdout; the contract is ONE JSON line there.  Route
+    # fd 1 to stderr until the result is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,8 +104,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SRI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL init, side-stream tip gather, full-panel
+    # gather) with whatever world size there is, even 1 — used to rehearse it on a one-GPU box.
+    use_dist = world > 1 or os.environ.get("SRI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -106,41 +125,45 @@ def main():
     which = sri.OP_DN if args.operator == "dn" else sri.OP_DNN_INV
     op = sri.SpectralApply(n, which, device=local_rank)
     rows, M = op.rows, 4 * rods
+    reserve = max(args.reserve_cus, 0)
+    if reserve > 0:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        op.set_max_workgroups(max(cus - reserve, 1))
 
     g = torch.Generator(device=dev).manual_seed(0x5EED + rank)
     X = torch.rand((M, rows), dtype=torch.float64, device=dev, generator=g) * 2 - 1   # synthetic U[-1,1) panel
     Y = torch.empty_like(X)
 
     # exchange step (N > 1): tips of step i gathered on a side stream under the apply of step i+1
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    tips_local = [torch.empty(M, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    tips_all = [torch.empty(M * world, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    full_all = torch.empty((M * world, rows), dtype=torch.float64, device=dev) if (world > 1 and args.gather == "full") else None
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    tips_local = [torch.empty(M, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    tips_all = [torch.empty(M * world, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    full_all = torch.empty((M * world, rows), dtype=torch.float64, device=dev) if (use_dist and args.gather == "full") else None
     ready = [torch.cuda.Event() for _ in range(2)]
     gathered = [torch.cuda.Event() for _ in range(2)]
 
     def step(i: int, ev_pair=None):
+        b = i & 1
+        tip_mode = use_dist and args.gather in ("tip", "final")
+        if use_dist and args.gather == "tip":
+            torch.cuda.current_stream().wait_event(gathered[b])       # tip buffer b free again
         if ev_pair is not None:
             ev_pair[0].record()
-        op.apply(X, out=Y)
+        op.apply(X, out=Y, tips=tips_local[b] if tip_mode else None)  # the epilogue emits the tip state itself
         if ev_pair is not None:
             ev_pair[1].record()
-        if world > 1 and args.gather != "none":
-            b = i & 1
-            if args.gather == "tip":
-                torch.cuda.current_stream().wait_event(gathered[b])   # buffer b free again
-                tips_local[b].copy_(Y[:, 0])
-                ready[b].record()
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ready[b])
-                    dist.all_gather_into_tensor(tips_all[b], tips_local[b])
-                    gathered[b].record()
-            else:
-                dist.all_gather_into_tensor(full_all, Y)
+        if use_dist and args.gather == "tip":
+            ready[b].record()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready[b])
+                dist.all_gather_into_tensor(tips_all[b], tips_local[b])
+                gathered[b].record()
+        elif use_dist and args.gather == "full":
+            dist.all_gather_into_tensor(full_all, Y)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,18 +181,28 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, events[i])
+    if use_dist and args.gather == "final":
+        # reassemble the final integrated state of the whole job: one RCCL all-gather over xGMI
+        dist.all_gather_into_tensor(tips_all[(args.steps - 1) & 1], tips_local[(args.steps - 1) & 1])
     fence()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
     # optional: one full-panel all-gather timed on its own (reported, never part of `value`)
     full_gather_ms = None
-    if world > 1 and args.gather == "tip":
+    tip_gather_ms = None
+    if use_dist and args.gather in ("tip", "final"):
+        dist.all_gather_into_tensor(tips_all[0], tips_local[0]); fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_gather_into_tensor(tips_all[0], tips_local[0])
+        fence()
+        tip_gather_ms = (time.perf_counter() - t1) * 1e3 / 10
         try:
             buf = torch.empty((M * world, rows), dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(buf, Y); fence()
@@ -211,10 +244,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n}, batch={rods} rods x 4 state columns per GPU, fp64, {args.operator} apply"
-                                   + (f", {world} GPUs sharded on the batch axis, RCCL all-gather of {args.gather} state" if world > 1 else ""),
+                                   + (f", {world} GPUs sharded on the batch axis, RCCL all-gather of {args.gather} state" if use_dist else ""),
                        "N": n, "rods_per_gpu": rods, "state_columns": 4, "operator": args.operator,
-                       "kernel": op.last_kernel, "gather": args.gather if world > 1 else "none",
-                       "clock_ramp_ms_untimed": args.ramp_ms},
+                       "kernel": op.last_kernel, "gather": args.gather if use_dist else "none",
+                       "clock_ramp_ms_untimed": args.ramp_ms,
+                       "cus_reserved_for_collective": reserve},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
@@ -225,11 +259,16 @@ def main():
         }
         if full_gather_ms is not None:
             out["full_panel_allgather_ms"] = full_gather_ms
+        if tip_gather_ms is not None:
+            out["tip_state_allgather_ms"] = tip_gather_ms
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,8 +43,10 @@ C_ABI = {
     "sri_ivp": (_int, [_u32, _u32, _dp, _dp, _dp, _sz]),
     "sri_apply_create": (_int, [C.POINTER(_vp), _u32, _int, _int]),
     "sri_apply_create_matrix": (_int, [C.POINTER(_vp), _u32, _dp, _sz, _int]),
+    "sri_apply_set_max_workgroups": (_int, [_vp, _u32]),
     "sri_apply_dim": (_int, [_vp, C.POINTER(_u32)]),
     "sri_apply": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp]),
+    "sri_apply_tips": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _vp]),
     "sri_integrate": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
     "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
@@ -213,8 +215,12 @@ class SpectralApply:
             raise ValueError(f"{name} is on cuda:{t.device.index}, operator on cuda:{self.device}")
         return t
 
-    def apply(self, X, out=None, stream=None):
-        """``Y = A @ X`` on the GPU (enqueued on torch's current stream unless ``stream`` is given)."""
+    def apply(self, X, out=None, stream=None, tips=None):
+        """``Y = A @ X`` on the GPU (enqueued on torch's current stream unless ``stream`` is given).
+
+        ``tips``: optional float64 CUDA tensor with one entry per column; receives ``Y[..., 0]``, the
+        tip-node value of every column, written by the kernel's epilogue.
+        """
         import torch
 
         X = self._panel(X, "X")
@@ -223,7 +229,13 @@ class SpectralApply:
             raise ValueError("out must have X's shape")
         M = X.numel() // self.rows
         s = torch.cuda.current_stream(X.device).cuda_stream if stream is None else stream
-        _chk(load_library().sri_apply(self._h, X.data_ptr(), self.rows, Y.data_ptr(), self.rows, M, s), "sri_apply")
+        if tips is None:
+            _chk(load_library().sri_apply(self._h, X.data_ptr(), self.rows, Y.data_ptr(), self.rows, M, s), "sri_apply")
+        else:
+            if not (tips.is_cuda and tips.dtype == torch.float64 and tips.is_contiguous() and tips.numel() == M):
+                raise ValueError("tips must be a contiguous float64 CUDA tensor with one entry per column")
+            _chk(load_library().sri_apply_tips(self._h, X.data_ptr(), self.rows, Y.data_ptr(), self.rows, M,
+                                               tips.data_ptr(), s), "sri_apply_tips")
         return Y
 
     __call__ = apply
@@ -255,6 +267,10 @@ class SpectralApply:
         Y = _fmat(*X.shape)
         _chk(load_library().sri_apply_host(self._h, _p(X), self.rows, _p(Y), self.rows, X.shape[1]), "sri_apply_host")
         return Y
+
+    def set_max_workgroups(self, n: int) -> None:
+        """Cap the persistent grid (0 = fill the chip): leaves CUs free for an overlapped collective."""
+        _chk(load_library().sri_apply_set_max_workgroups(self._h, int(n)), "sri_apply_set_max_workgroups")
 
     @property
     def last_kernel(self) -> str:

@@ -97,6 +97,7 @@ struct ApplyArgs {
   double* y;
   const double* w;       // optional rank-1 epilogue: y -= w[row] * xb[col]   (w padded to row_blocks*BM)
   const double* xb;
+  double* tips;          // optional: tips[col] = Y[0][col], the rod-tip node (chebyshev_differentiation.h:26: x_0 = L)
   size_t ldx, ldy, m;    // m = number of columns
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
@@ -339,6 +340,23 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   // ---- Y stores of a finished tile (registers -> HBM, no LDS, no wait) --------------------------
   // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
+  // Optional by-product: the tip-node value of every column (row 0 of the first row block), the "final
+  // integrated state" a multi-GPU run reassembles.  Row 0 sits in acc[0][tn][r] of the lanes with c == 0.
+  auto emit_tips = [&](uint32_t rb, size_t col_base) __attribute__((always_inline)) {
+    if (p.tips == nullptr || rb != 0 || wm != 0) return;      // wave-uniform
+    if (c != 0) return;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t col = col_base + tn * 16 + r * 4;
+        if (col < p.m) {
+          double v = acc[0][tn][r];
+          if constexpr (RANK1) v -= p.w[0] * p.xb[col];
+          p.tips[col] = v;
+        }
+      }
+  };
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     const uint32_t rb_c = tile / p.col_tiles;
     const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
@@ -370,6 +388,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             }
             *reinterpret_cast<d2*>(yp) = d2{v0, v1};
           }
+      emit_tips(rb_c, col_base);
       return true;
     } else {
 #pragma unroll
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             }
           }
         }
+      emit_tips(rb_c, col_base);
       return false;
     }
   };
@@ -595,6 +615,7 @@ struct sri_apply_handle {
   int geo = 0;
   uint32_t bm = 0, nk = 0, row_blocks = 0;
   int num_cus = 0;
+  uint32_t max_workgroups = 0;   // 0 = fill the chip; else cap of the persistent grid (leave CUs to a collective)
   double* d_apack = nullptr;
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   const char* last_kernel = "none";
@@ -622,7 +643,7 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.  The residency number is queried once per kernel variant and device.
 template <class G, bool DMA, bool RANK1>
-static int launch(ApplyArgs args, size_t col_tiles, int num_cus, hipStream_t stream) {
+static int launch(ApplyArgs args, size_t col_tiles, int num_cus, uint32_t max_wgs, hipStream_t stream) {
   static int blocks_per_cu[16] = {};   // per device; 0 = not queried yet
   int dev = 0;
   SRI_HIP(hipGetDevice(&dev));
@@ -639,7 +660,8 @@ static int launch(ApplyArgs args, size_t col_tiles, int num_cus, hipStream_t str
   if (tiles == 0) return SRI_OK;
   if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
   args.col_tiles = static_cast<uint32_t>(col_tiles);
-  const size_t resident = static_cast<size_t>(num_cus) * blocks_per_cu[dev];
+  size_t resident = static_cast<size_t>(num_cus) * blocks_per_cu[dev];
+  if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
   SRI_HIP(hipGetLastError());
@@ -650,10 +672,11 @@ template <class G>
 static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
   const int cus = h->num_cus;
-  if (dma && rank1) return launch<G, true, true>(args, col_tiles, cus, stream);
-  if (dma) return launch<G, true, false>(args, col_tiles, cus, stream);
-  if (rank1) return launch<G, false, true>(args, col_tiles, cus, stream);
-  return launch<G, false, false>(args, col_tiles, cus, stream);
+  const uint32_t cap = h->max_workgroups;
+  if (dma && rank1) return launch<G, true, true>(args, col_tiles, cus, cap, stream);
+  if (dma) return launch<G, true, false>(args, col_tiles, cus, cap, stream);
+  if (rank1) return launch<G, false, true>(args, col_tiles, cus, cap, stream);
+  return launch<G, false, false>(args, col_tiles, cus, cap, stream);
 }
 
 static const char* kernel_name(int geo, bool dma) {
@@ -748,7 +771,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
 }
 
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
-               hipStream_t stream) {
+               hipStream_t stream, double* d_tips = nullptr) {
   if (h == nullptr || (M > 0 && (dX == nullptr || dY == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
   if (M == 0) return SRI_OK;
   const bool rank1 = d_xb != nullptr;
@@ -763,6 +786,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.y = dY;
   args.w = h->d_w;
   args.xb = d_xb;
+  args.tips = d_tips;
   args.ldx = ldx;
   args.ldy = ldy;
   args.m = M;
@@ -829,6 +853,12 @@ int sri_apply_create_matrix(sri_apply_t** out, uint32_t rows, const double* A, s
   return sri::create_from_matrix(out, rows, A, lda, nullptr, -1, device);
 }
 
+int sri_apply_set_max_workgroups(sri_apply_t* h, uint32_t max_workgroups) {
+  if (h == nullptr) return SRI_EINVAL;
+  h->max_workgroups = max_workgroups;
+  return SRI_OK;
+}
+
 int sri_apply_dim(const sri_apply_t* h, uint32_t* rows) {
   if (h == nullptr || rows == nullptr) return SRI_EINVAL;
   *rows = h->rows;
@@ -837,6 +867,12 @@ int sri_apply_dim(const sri_apply_t* h, uint32_t* rows) {
 
 int sri_apply(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, void* hip_stream) {
   return sri::run(h, dX, ldx, dY, ldy, M, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+int sri_apply_tips(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, double* d_tips,
+                   void* hip_stream) {
+  if (d_tips == nullptr) return SRI_EINVAL;
+  return sri::run(h, dX, ldx, dY, ldy, M, nullptr, static_cast<hipStream_t>(hip_stream), d_tips);
 }
 
 int sri_integrate(sri_apply_t* h, const double* dB, size_t ldb, const double* d_x_base, double* dY, size_t ldy,

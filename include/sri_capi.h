@@ -94,6 +94,11 @@ int sri_apply_create(sri_apply_t **out, uint32_t n, int which, int device);
 /* Same, for a caller-supplied square matrix A (rows x rows, column-major, lda >= rows). */
 int sri_apply_create_matrix(sri_apply_t **out, uint32_t rows, const double *A, size_t lda, int device);
 
+/* Cap the number of persistent workgroups a launch uses (0 = fill the chip, the default).  The apply
+ * kernel occupies every CU for the whole launch; a caller that overlaps a collective (RCCL) with it
+ * leaves a few CUs free this way so that the collective's kernel can run concurrently. */
+int sri_apply_set_max_workgroups(sri_apply_t *h, uint32_t max_workgroups);
+
 /* rows (= cols) of the operator held by the handle: n for SRI_OP_DN, n-1 otherwise. */
 int sri_apply_dim(const sri_apply_t *h, uint32_t *rows);
 
@@ -103,6 +108,12 @@ int sri_apply_dim(const sri_apply_t *h, uint32_t *rows);
  * dimensions and rows % 16 == 0 take the LDS-DMA fast path). */
 int sri_apply(sri_apply_t *h, const double *dX, size_t ldx, double *dY, size_t ldy, size_t M,
               void *hip_stream);
+
+/* sri_apply that additionally writes the tip-node value of every column, d_tips[j] = Y[0][j]
+ * (node 0 is the rod tip X = L: chebyshev_differentiation.h:26), M device doubles.  This is the "final
+ * integrated state" a multi-GPU run all-gathers; emitted by the kernel's epilogue at no extra traffic. */
+int sri_apply_tips(sri_apply_t *h, const double *dX, size_t ldx, double *dY, size_t ldy, size_t M,
+                   double *d_tips, void *hip_stream);
 
 /* Position/quaternion integration in one call, main.cpp:172 batched:
  *   Y = Dnn_inv * (B - Din * x_base^T)

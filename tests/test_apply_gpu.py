@@ -169,6 +169,23 @@ def test_integrate_matches_oracle(sri, oracle, n):
     assert np.max(np.abs(Y - Yref) / scale) <= backward_tol(n)
 
 
+@pytest.mark.parametrize("n,which,M", [(256, 0, 1000), (64, 0, 777), (256, 1, 130), (1024, 0, 129)])
+def test_apply_tips_is_row0_of_the_result(sri, n, which, M):
+    """sri_apply_tips: the kernel's epilogue also emits Y[0, :] (the rod-tip node), bit-identical to Y."""
+    import torch
+
+    op = sri.SpectralApply(n, which)
+    X = torch.rand((M, op.rows), dtype=torch.float64, device="cuda") * 2 - 1
+    tips = torch.full((M,), 7.0, dtype=torch.float64, device="cuda")
+    Y = op.apply(X, tips=tips)
+    Y2 = op.apply(X)
+    torch.cuda.synchronize()
+    assert torch.equal(Y, Y2)
+    assert torch.equal(tips, Y[:, 0].contiguous())
+    with pytest.raises(ValueError):
+        op.apply(X, tips=tips[:-1])
+
+
 def test_apply_host_roundtrip(sri, oracle):
     n, M = 64, 300
     A = oracle.dn(n)
