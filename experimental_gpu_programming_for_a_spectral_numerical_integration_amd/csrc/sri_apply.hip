@@ -640,30 +640,50 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
             }
 }
 
-// Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
-// than there are tiles.  The residency number is queried once per kernel variant and device.
+// Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
+// that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
+// inside a stream capture (HIP graph).
 template <class G, bool DMA, bool RANK1>
-static int launch(ApplyArgs args, size_t col_tiles, int num_cus, uint32_t max_wgs, hipStream_t stream) {
-  static int blocks_per_cu[16] = {};   // per device; 0 = not queried yet
-  int dev = 0;
-  SRI_HIP(hipGetDevice(&dev));
+static int& residency(int dev) {
+  static int blocks_per_cu[16] = {};
+  return blocks_per_cu[dev];
+}
+
+template <class G, bool DMA, bool RANK1>
+static int prepare(int dev) {
   if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
+  if (residency<G, DMA, RANK1>(dev) != 0) return SRI_OK;
   const auto kern = &apply_kernel<G, DMA, RANK1>;
-  if (blocks_per_cu[dev] == 0) {
-    SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                G::LDS_BYTES));
-    int nb = 0;
-    SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
-    blocks_per_cu[dev] = nb < 1 ? 1 : nb;
-  }
+  SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  int nb = 0;
+  SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
+  residency<G, DMA, RANK1>(dev) = nb < 1 ? 1 : nb;
+  return SRI_OK;
+}
+
+template <class G>
+static int prepare_geometry(int dev) {
+  int rc = prepare<G, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true>(dev);
+  if (rc == SRI_OK) rc = prepare<G, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, false, true>(dev);
+  return rc;
+}
+
+// Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
+// than there are tiles.
+template <class G, bool DMA, bool RANK1>
+static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream) {
+  const int per_cu = residency<G, DMA, RANK1>(dev);
+  if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;
   if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
   args.col_tiles = static_cast<uint32_t>(col_tiles);
-  size_t resident = static_cast<size_t>(num_cus) * blocks_per_cu[dev];
+  size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
+  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -671,12 +691,12 @@ static int launch(ApplyArgs args, size_t col_tiles, int num_cus, uint32_t max_wg
 template <class G>
 static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
-  const int cus = h->num_cus;
+  const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
-  if (dma && rank1) return launch<G, true, true>(args, col_tiles, cus, cap, stream);
-  if (dma) return launch<G, true, false>(args, col_tiles, cus, cap, stream);
-  if (rank1) return launch<G, false, true>(args, col_tiles, cus, cap, stream);
-  return launch<G, false, false>(args, col_tiles, cus, cap, stream);
+  if (dma && rank1) return launch<G, true, true>(args, col_tiles, dev, cus, cap, stream);
+  if (dma) return launch<G, true, false>(args, col_tiles, dev, cus, cap, stream);
+  if (rank1) return launch<G, false, true>(args, col_tiles, dev, cus, cap, stream);
+  return launch<G, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
 static const char* kernel_name(int geo, bool dma) {
@@ -740,6 +760,12 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->bm = h->geo == GEO_FLAT ? GeoFlat::BM : (h->geo == GEO_MID ? GeoMid::BM : GeoTall::BM);
   h->nk = (rows + BK - 1) / BK;
   h->row_blocks = (rows + h->bm - 1) / h->bm;
+  rc = h->geo == GEO_FLAT ? prepare_geometry<GeoFlat>(device)
+                          : (h->geo == GEO_MID ? prepare_geometry<GeoMid>(device) : prepare_geometry<GeoTall>(device));
+  if (rc != SRI_OK) {
+    delete h;
+    return rc;
+  }
 
   std::vector<double> packed;
   try {

@@ -186,6 +186,32 @@ def test_apply_tips_is_row0_of_the_result(sri, n, which, M):
         op.apply(X, tips=tips[:-1])
 
 
+def test_apply_is_graph_capturable(sri):
+    """sri_apply only enqueues a kernel (no allocation, attribute call or sync): capture it in a HIP graph."""
+    import torch
+
+    n, M = 256, 4096
+    op = sri.SpectralApply(n, 0)
+    X = torch.rand((M, n), dtype=torch.float64, device="cuda") * 2 - 1
+    Y = torch.zeros_like(X)
+    ref = op.apply(X)                                  # eager result
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            op.apply(X, out=Y)
+    Y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Y, ref)
+    X.mul_(0.5)                                        # same buffers, new contents: replay must recompute
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Y, op.apply(X))
+
+
 def test_apply_host_roundtrip(sri, oracle):
     n, M = 64, 300
     A = oracle.dn(n)
