@@ -103,6 +103,7 @@ struct ApplyArgs {
   uint32_t nk;           // k chunks
   uint32_t row_blocks;
   uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
+  uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
 };
 
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // piece position (lane & 7) of column 8i + (lane >> 3), which must hold source piece
   // (lane & 7) ^ sigma(column).
   const char* xsrc[DMA ? G::X_DMA_PER_WAVE : 1];
+  int xsafe[DMA ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
   const char* asrc;
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
   size_t col0_i = 0;
@@ -194,6 +196,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         size_t col = col0_i + cc;
         col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
         xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
+        // In the last k chunk of a panel whose row count is not a multiple of 16, a piece that holds a k
+        // beyond the last row must not be fetched from where it "would be" (that is the next column, or past
+        // the end of the buffer): it is fetched from the same piece of the PREVIOUS chunk instead (a full chunk
+        // of the same column: rows >= 17 here) and its LDS image is rewritten by fixup_tail() before use.
+        xsafe[it] = (p.tail_k != 0 && 2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -220,7 +227,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
           const int i = wid + it * NW;
-          lds_dma16(xsrc[it] + static_cast<size_t>(kc_i) * X_ROW_BYTES, sX + i * 1024);
+          const int back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
+          lds_dma16(xsrc[it] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sX + i * 1024);
         }
       }
       if constexpr (ABL != 0) abl_first = false;
@@ -248,7 +256,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       if (!(ABL & 2) || abl_first) {
         const int it = idx - G::A_DMA_PER_WAVE;
         const int i = wid + it * NW;
-        lds_dma16(xsrc[DMA ? it : 0] + static_cast<size_t>(kc_i) * X_ROW_BYTES, sA + G::A_BYTES + i * 1024);
+        const int back = (kc_i + 1 == p.nk) ? xsafe[DMA ? it : 0] : 0;
+        lds_dma16(xsrc[DMA ? it : 0] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sA + G::A_BYTES + i * 1024);
       }
       if constexpr (ABL != 0) { if (idx == G::DMA_PER_WAVE - 1) abl_first = false; }
     }
@@ -362,7 +371,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
     const size_t col_base = col0_c + wn * (TN * 16) + g;
-    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows);
+    // "full": every column of the tile exists and at most the very last row of the row block is missing
+    // (rows = 255, 1023, 63, ...).  Then every wave issues at least NSTORE store instructions, which is
+    // what the counted waits of the stage stream rely on.
+    const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
+    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
     if constexpr ((ABL & 4) != 0) {
       // ablation: keep the accumulators live, store nothing
 #pragma unroll
@@ -371,7 +384,6 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
       return false;
     } else if (full) {
-      // every lane stores: exactly NSTORE dwordx4 stores per wave, which the counted waits rely on
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -379,14 +391,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const size_t col = col_base + tn * 16 + r * 4;
-            double* yp = p.y + col * p.ldy + row_base + 32 * t;
+            const uint32_t row = row_base + 32 * t;
+            double* yp = p.y + col * p.ldy + row;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
             if constexpr (RANK1) {
               const double xbv = p.xb[col];
-              v0 -= p.w[row_base + 32 * t] * xbv;
-              v1 -= p.w[row_base + 32 * t + 1] * xbv;
+              v0 -= p.w[row] * xbv;
+              v1 -= p.w[row + 1] * xbv;          // w is zero padded
             }
-            *reinterpret_cast<d2*>(yp) = d2{v0, v1};
+            if (all_rows || row + 1 < p.rows) *reinterpret_cast<d2*>(yp) = d2{v0, v1};   // 16 B, 8-byte aligned is fine
+            else *yp = v0;                                                             // the lane holding the last row
           }
       emit_tips(rb_c, col_base);
       return true;
@@ -408,8 +422,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
               if (row < p.rows) v0 -= p.w[row] * xbv;
               if (row + 1 < p.rows) v1 -= p.w[row + 1] * xbv;
             }
-            if constexpr (DMA) {
-              if (row < p.rows) *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
+            if (DMA && row + 1 < p.rows) {
+              *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
             } else {
               if (row < p.rows) ycol[row] = v0;
               if (row + 1 < p.rows) ycol[row + 1] = v1;
@@ -459,13 +473,42 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   // wait(s) + barrier(s).  Ops of this wave younger than stage s's DMA: the DMA of stage s+1, plus a full
   // tile's stores if they were issued after stage s's DMA, i.e. within the last two bodies.
-  auto wait_stage = [&](auto refill_tag) __attribute__((always_inline)) {
+  // Last k chunk of a tile when rows % 16 != 0: rewrite, in the LDS image of the stage that just landed, every
+  // 16-byte piece that holds a k beyond the last row — from plain bounds-checked loads, zero for k >= rows (so
+  // that no foreign value, possibly NaN/Inf, ever meets the zero padding of the operator).  A handful of
+  // elements per column, once per tile, fenced by one extra barrier that both wave groups execute.
+  auto fixup_tail = [&](uint32_t slot, uint32_t tile_s) __attribute__((always_inline)) {
+    char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
+    const uint32_t k0 = p.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
+    const uint32_t fixn = BK - k0;                           // elements per column to rewrite
+    const size_t col0_s = static_cast<size_t>(tile_s % p.col_tiles) * G::BN;
+    const uint32_t kbase = (p.nk - 1) * BK;
+    for (uint32_t idx = tid; idx < G::BN * fixn; idx += G::THREADS) {
+      const uint32_t cc = idx / fixn, kk = k0 + idx % fixn;
+      const size_t col = col0_s + cc;
+      double v = 0.0;
+      if (col < p.m && kbase + kk < p.rows) v = p.x[col * p.ldx + kbase + kk];
+      const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & 7);
+      *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // wait(s) + barrier(s) for the stage (tile_s, kc_s) in ring slot `slot`.  Ops of this wave younger than
+  // stage s's DMA: the DMA of stage s+1, plus a full tile's stores if they were issued after stage s's DMA,
+  // i.e. within the last two bodies.
+  auto wait_stage = [&](auto refill_tag, uint32_t slot, uint32_t kc_s, uint32_t tile_s) __attribute__((always_inline)) {
     if (decltype(refill_tag)::value) {
       if (since_store < 2) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<W_STEADY>();
     } else {
       wait_stage_and_barrier<0>();                         // tail of the stream: fewer stages in flight
     }
     if (since_store < 99) ++since_store;
+    if constexpr (DMA) {
+      if (p.tail_k != 0 && kc_s + 1 == p.nk) fixup_tail(slot, tile_s);
+    }
     if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
   };
   // Y stores of `tile` + accumulators back to zero
@@ -504,7 +547,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool REFILL = decltype(refill_tag)::value;
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
-      wait_stage(refill_tag);
+      wait_stage(refill_tag, slot_c, kc_c, tile_c);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
@@ -534,7 +577,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool REFILL = decltype(refill_tag)::value;
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
-      wait_stage(refill_tag);
+      wait_stage(refill_tag, slot_c, kc_c, tile_c);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
@@ -555,10 +598,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       using PT = std::integral_constant<bool, PIECES>;
       int piece = 0;
       mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
-      wait_stage(refill_tag);
+      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+      const bool wraps = kc_c + 1 == p.nk;                           // stage s opens the next tile
+      wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + gridDim.x : tile_c);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
-      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
       read_pair(next_slot, 0, pa, pb);                               // (s, 0): landed, consumed 7 groups later
       mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
@@ -822,8 +866,12 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.col_tiles = 0;   // set by launch()
   args.stamps = nullptr;
 
-  const bool dma = (h->rows % 16 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) &&
-                   (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (reinterpret_cast<uintptr_t>(dY) % 16 == 0);
+  // LDS-DMA (16 bytes per lane) and 16-byte stores work at 8-byte alignment on gfx950 at ~96 % of the aligned
+  // rate (tools/unaligned_probe.hip), so any fp64 panel takes the DMA path; a row count that is not a multiple
+  // of 16 is handled by the tail fix-up.  Only tiny operators (< 16 rows: no full chunk to fall back on) use
+  // the register-staged build.
+  const bool dma = h->rows >= 16;
+  args.tail_k = h->rows % 16;
   h->last_kernel = kernel_name(h->geo, dma);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream);
