@@ -20,7 +20,7 @@ import numpy as np
 __all__ = [
     "SriError", "build_library", "library_path", "load_library",
     "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
-    "SpectralApply", "OP_DN", "OP_DNN_INV", "OP_DNN",
+    "SpectralApply", "RodIntegrator", "OP_DN", "OP_DNN_INV", "OP_DNN",
 ]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -48,9 +48,18 @@ C_ABI = {
     "sri_apply": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp]),
     "sri_apply_tips": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _vp]),
     "sri_integrate": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp]),
+    "sri_integrate_tips": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
     "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
     "sri_apply_destroy": (_int, [_vp]),
+    "sri_rod_create": (_int, [C.POINTER(_vp), _u32, _int]),
+    "sri_rod_destroy": (_int, [_vp]),
+    "sri_rod_strain_field": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
+    "sri_rod_integrate_positions": (_int, [_vp, _vp, _sz, _sz, _dp, _vp, _sz, _vp]),
+    "sri_rod_integrate": (_int, [_vp, _vp, _sz, _dp, _dp, _vp, _sz, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
     "sri_apply_last_kernel": (C.c_char_p, [_vp]),
     "sri_strerror": (C.c_char_p, [_int]),
     "sri_last_hip_error": (_int, []),
@@ -279,6 +288,95 @@ class SpectralApply:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             load_library().sri_apply_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# Batched rod integration: main.cpp's integrateQuaternions + integratePosition
+# ------------------------------------------------------------------------------------------------
+class RodIntegrator:
+    """Integrates a batch of Cosserat rods on the GPU, given their strain coordinates ``qe``.
+
+    ``qe``: float64 CUDA tensor ``(rods, 9)`` in the order of main.cpp:187-195.  Results are panels
+    ``Q (rods, 4, N-1)`` (w, x, y, z at the unknown nodes, tip first) and ``r (rods, 3, N-1)`` — the
+    column-major ``(N-1) x 4`` / ``(N-1) x 3`` matrices main.cpp prints, one per rod.
+    """
+
+    def __init__(self, n: int, device: int = 0):
+        self._h = _vp()
+        self.n, self.m, self.device = int(n), int(n) - 1, int(device)
+        _chk(load_library().sri_rod_create(C.byref(self._h), self.n, self.device), "sri_rod_create")
+        self.iterations = 0
+        self.last_update = 0.0
+
+    def _stream(self, t):
+        import torch
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def _check_qe(self, qe):
+        import torch
+        if not (isinstance(qe, torch.Tensor) and qe.is_cuda and qe.dtype == torch.float64 and qe.is_contiguous()
+                and qe.dim() == 2 and qe.shape[1] == 9 and qe.device.index == self.device):
+            raise TypeError("qe must be a contiguous float64 CUDA tensor of shape (rods, 9) on the handle's device")
+        return qe
+
+    def strain_field(self, qe):
+        import torch
+        qe = self._check_qe(qe)
+        K = torch.empty((qe.shape[0], 3, self.m), dtype=torch.float64, device=qe.device)
+        _chk(load_library().sri_rod_strain_field(self._h, qe.data_ptr(), qe.shape[0], K.data_ptr(), self.m, self._stream(qe)),
+             "sri_rod_strain_field")
+        return K
+
+    def quaternion_rhs(self, K, Q):
+        import torch
+        G = torch.empty_like(Q)
+        _chk(load_library().sri_rod_quaternion_rhs(self._h, K.data_ptr(), self.m, Q.data_ptr(), self.m, Q.shape[0],
+                                                   G.data_ptr(), self.m, self._stream(Q)), "sri_rod_quaternion_rhs")
+        return G
+
+    def position_rhs(self, Q):
+        import torch
+        B = torch.empty((Q.shape[0], 3, self.m), dtype=torch.float64, device=Q.device)
+        _chk(load_library().sri_rod_position_rhs(self._h, Q.data_ptr(), self.m, Q.shape[0], B.data_ptr(), self.m,
+                                                 self._stream(Q)), "sri_rod_position_rhs")
+        return B
+
+    def integrate_quaternions(self, qe, q_init=None, tol: float = 1e-14, max_iter: int = 200):
+        import torch
+        qe = self._check_qe(qe)
+        rods = qe.shape[0]
+        Q = torch.empty((rods, 4, self.m), dtype=torch.float64, device=qe.device)
+        qi = None if q_init is None else (C.c_double * 4)(*[float(v) for v in q_init])
+        it, upd = _u32(), C.c_double()
+        rc = load_library().sri_rod_integrate_quaternions(self._h, qe.data_ptr(), rods, qi, Q.data_ptr(), self.m, tol, max_iter,
+                                                          C.byref(it), C.byref(upd), self._stream(qe))
+        self.iterations, self.last_update = int(it.value), float(upd.value)
+        _chk(rc, "sri_rod_integrate_quaternions")
+        return Q
+
+    def integrate_positions(self, Q, r_init=None):
+        import torch
+        rods = Q.shape[0]
+        R = torch.empty((rods, 3, self.m), dtype=torch.float64, device=Q.device)
+        ri = None if r_init is None else (C.c_double * 3)(*[float(v) for v in r_init])
+        _chk(load_library().sri_rod_integrate_positions(self._h, Q.data_ptr(), self.m, rods, ri, R.data_ptr(), self.m,
+                                                        self._stream(Q)), "sri_rod_integrate_positions")
+        return R
+
+    def integrate(self, qe, q_init=None, r_init=None, tol: float = 1e-14, max_iter: int = 200):
+        Q = self.integrate_quaternions(qe, q_init, tol, max_iter)
+        return Q, self.integrate_positions(Q, r_init)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load_library().sri_rod_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

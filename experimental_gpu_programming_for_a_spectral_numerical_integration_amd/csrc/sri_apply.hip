@@ -46,6 +46,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 static thread_local int g_last_hip_error = 0;
+void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 
 #define SRI_HIP(call)                                            \
   do {                                                           \
@@ -384,24 +385,35 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
       return false;
     } else if (full) {
+      // rank-1 term: this lane's TM row factors once per tile, one x_base value per column (not per store)
+      double wv[TM / 2][2];
+      if constexpr (RANK1) {
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t) {
+          wv[t][0] = p.w[row_base + 32 * t];
+          wv[t][1] = p.w[row_base + 32 * t + 1];   // w is zero padded
+        }
+      }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int t = 0; t < TM / 2; ++t)
+        for (int r = 0; r < 4; ++r) {
+          const size_t col = col_base + tn * 16 + r * 4;
+          double xbv = 0.0;
+          if constexpr (RANK1) xbv = p.xb[col];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const size_t col = col_base + tn * 16 + r * 4;
+          for (int t = 0; t < TM / 2; ++t) {
             const uint32_t row = row_base + 32 * t;
             double* yp = p.y + col * p.ldy + row;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
             if constexpr (RANK1) {
-              const double xbv = p.xb[col];
-              v0 -= p.w[row] * xbv;
-              v1 -= p.w[row + 1] * xbv;          // w is zero padded
+              v0 -= wv[t][0] * xbv;
+              v1 -= wv[t][1] * xbv;
             }
             if (all_rows || row + 1 < p.rows) *reinterpret_cast<d2*>(yp) = d2{v0, v1};   // 16 B, 8-byte aligned is fine
             else *yp = v0;                                                             // the lane holding the last row
           }
+        }
       emit_tips(rb_c, col_base);
       return true;
     } else {
@@ -947,6 +959,12 @@ int sri_apply_tips(sri_apply_t* h, const double* dX, size_t ldx, double* dY, siz
                    void* hip_stream) {
   if (d_tips == nullptr) return SRI_EINVAL;
   return sri::run(h, dX, ldx, dY, ldy, M, nullptr, static_cast<hipStream_t>(hip_stream), d_tips);
+}
+
+int sri_integrate_tips(sri_apply_t* h, const double* dB, size_t ldb, const double* d_x_base, double* dY, size_t ldy, size_t M,
+                       double* d_tips, void* hip_stream) {
+  if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr || d_tips == nullptr) return SRI_EINVAL;
+  return sri::run(h, dB, ldb, dY, ldy, M, d_x_base, static_cast<hipStream_t>(hip_stream), d_tips);
 }
 
 int sri_integrate(sri_apply_t* h, const double* dB, size_t ldb, const double* d_x_base, double* dY, size_t ldy,

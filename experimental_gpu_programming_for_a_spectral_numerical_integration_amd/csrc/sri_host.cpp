@@ -187,6 +187,7 @@ const char* sri_strerror(int status) {
     case SRI_EHIP: return "HIP runtime error";
     case SRI_ENODEVICE: return "no usable HIP device";
     case SRI_EUNSUPPORTED: return "unsupported request";
+    case SRI_ENOTCONVERGED: return "fixed-point iteration did not converge";
     default: return "unknown sri_status";
   }
 }

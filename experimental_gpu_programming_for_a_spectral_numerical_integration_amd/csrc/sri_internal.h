@@ -18,6 +18,9 @@ int dense_inverse(uint32_t m, const double* A, size_t lda, double* Ainv, size_t 
 int cheb_integration(uint32_t n, double* Dnn_inv, size_t ld, double* Din);
 int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double* out, size_t ld);
 
+// ---- error bookkeeping (sri_apply.hip): what sri_last_hip_error() reports -----------------------
+void record_hip_error(int hip_error);
+
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------
 // One v_mfma_f64_16x16x4_f64 computes D[i][j] += sum_k P[i][k] Q[k][j] (i, j < 16, k < 4); lane l feeds
 // P[l & 15][l >> 4] and Q[l >> 4][l & 15] and receives D[(l >> 4) + 4*reg][l & 15], reg = 0..3.

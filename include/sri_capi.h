@@ -39,7 +39,8 @@ typedef enum sri_status {
     SRI_ESINGULAR = -3,    /* zero pivot while inverting Dn_NN                                 */
     SRI_EHIP = -4,         /* a HIP runtime call failed (sri_last_hip_error() has the code)   */
     SRI_ENODEVICE = -5,    /* no gfx950 device / bad device ordinal                           */
-    SRI_EUNSUPPORTED = -6  /* valid request this build cannot serve                           */
+    SRI_EUNSUPPORTED = -6, /* valid request this build cannot serve                           */
+    SRI_ENOTCONVERGED = -7 /* sri_rod_integrate_quaternions: update still above tol at max_iter */
 } sri_status;
 
 /* Which constant left-hand matrix an apply handle holds. */
@@ -123,6 +124,10 @@ int sri_apply_tips(sri_apply_t *h, const double *dX, size_t ldx, double *dY, siz
 int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
                   double *dY, size_t ldy, size_t M, void *hip_stream);
 
+/* sri_integrate that also emits the tip-node value of every column (see sri_apply_tips). */
+int sri_integrate_tips(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
+                       double *dY, size_t ldy, size_t M, double *d_tips, void *hip_stream);
+
 /* Convenience for callers holding HOST buffers: stages X through device memory, applies,
  * copies Y back, synchronises.  (PCIe-inclusive; never what bench.py times.) */
 int sri_apply_host(sri_apply_t *h, const double *X, size_t ldx, double *Y, size_t ldy, size_t M);
@@ -132,6 +137,47 @@ int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double
                        double *Y, size_t ldy, size_t M);
 
 int sri_apply_destroy(sri_apply_t *h);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Batched rod integration: the callers on either side of the apply, device-resident          */
+/* (SURVEY.md §8f rows 1-2).  m = n-1 unknown nodes; panels are column-major m x (s*rods):     */
+/* per rod 3 columns of K, 4 of Q (w,x,y,z), 3 of b / r.  All pointers are DEVICE pointers.    */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct sri_rod_handle sri_rod_t;
+
+/* Owns Dn_NN^-1 (an SRI_OP_DNN_INV apply handle), the Chebyshev nodes and a workspace. */
+int sri_rod_create(sri_rod_t **out, uint32_t n, int device);
+int sri_rod_destroy(sri_rod_t *h);
+
+/* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):
+ * d_qe: 9 doubles per rod in main.cpp:187-195 order; dK: m x (3*rods), ldk >= m. */
+int sri_rod_strain_field(sri_rod_t *h, const double *d_qe, size_t rods, double *dK, size_t ldk, void *hip_stream);
+
+/* G_i = 1/2 A(K_i) Q_i per node (main.cpp:71-84). */
+int sri_rod_quaternion_rhs(sri_rod_t *h, const double *dK, size_t ldk, const double *dQ, size_t ldq, size_t rods,
+                           double *dG, size_t ldg, void *hip_stream);
+
+/* b_i = R(q_i) e1, updatePositionb (main.cpp:121-140). */
+int sri_rod_position_rhs(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods, double *dB, size_t ldb,
+                         void *hip_stream);
+
+/* integrateQuaternions (main.cpp:91-118) for a batch: solves (I_4 (x) Dn_NN - 1/2 A(K)) Q = -D_IN q_init by the
+ * fixed-point form Q <- Dn_NN^-1 (1/2 A(K) Q - Dn_IN q_init^T) on the MFMA integration apply, until the largest
+ * update of any entry is <= tol (or max_iter: SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).
+ * dQ: m x (4*rods).  Synchronises the stream once per iteration (convergence read-back). */
+int sri_rod_integrate_quaternions(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, double *dQ,
+                                  size_t ldq, double tol, uint32_t max_iter, uint32_t *iters, double *last_update,
+                                  void *hip_stream);
+
+/* integratePosition (main.cpp:145-176) for a batch: r = Dn_NN^-1 (R(q) e1 - Dn_IN r_init^T).  r_init: 3 HOST
+ * doubles (NULL = 0,0,0).  dR: m x (3*rods). */
+int sri_rod_integrate_positions(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods, const double *r_init,
+                                double *dR, size_t ldr, void *hip_stream);
+
+/* Both, i.e. what main() computes for its one rod (main.cpp:197-201), for `rods` rods. */
+int sri_rod_integrate(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, const double *r_init,
+                      double *dQ, size_t ldq, double *dR, size_t ldr, double tol, uint32_t max_iter,
+                      uint32_t *iters, double *last_update, void *hip_stream);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Introspection / diagnostics                                                              */

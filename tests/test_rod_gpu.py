@@ -1,0 +1,106 @@
+"""GPU parity of the widened rows: batched strain field, quaternion integration
+(fixed point on the integration apply) and position integration, against the oracle's restatement of
+main.cpp:55-176 (dense per-rod solve)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _qe_batch(rods, seed=0x5EED, scale=2.0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-scale, scale, size=(rods, 9))
+
+
+def _oracle_rods(oracle, n, qe, q_init=None, r_init=None):
+    Q = np.stack([np.ascontiguousarray(oracle.integrate_quaternions(n, q, q_init).T) for q in qe])      # (rods, 4, m)
+    R = np.stack([np.ascontiguousarray(oracle.integrate_position(n, np.asfortranarray(Qi.T), r_init).T) for Qi in Q])
+    return Q, R
+
+
+def test_config1_rod_of_main_cpp(sri, oracle):
+    """BASELINE config 1 entirely on the device: N=16, the hard-coded qe of main.cpp:187-195."""
+    import torch
+
+    rod = sri.RodIntegrator(16)
+    qe = torch.from_numpy(oracle.QE_MAIN_CPP[None, :].copy()).cuda()
+    Q, R = rod.integrate(qe)
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, 16, oracle.QE_MAIN_CPP[None, :])
+    assert np.abs(Q.cpu().numpy() - Qo).max() <= 1e-13
+    assert np.abs(R.cpu().numpy() - Ro).max() <= 1e-13
+    assert 5 <= rod.iterations <= 40 and rod.last_update <= 1e-14
+    # physics anchor: planar bend, tip angle theta(1) = qe[3]
+    assert abs(Q[0, 0, 0].item() - 0.7997698672530426) <= 1e-13 and abs(R[0, 2, 0].item() + 0.74591365968166945) <= 1e-13
+
+
+@pytest.mark.parametrize("n,rods", [(16, 64), (64, 12), (32, 33)])
+def test_batched_rods_match_oracle(sri, oracle, n, rods):
+    import torch
+
+    qe = _qe_batch(rods)
+    rod = sri.RodIntegrator(n)
+    dqe = torch.from_numpy(qe).cuda()
+    # strain field and RHS builders are bit-identical to the oracle's arithmetic
+    K = rod.strain_field(dqe).cpu().numpy()
+    x = oracle.points(n)
+    Ko = np.stack([np.stack([oracle.strain(x[i], q) for i in range(n - 1)], axis=1) for q in qe])            # (rods, 3, m)
+    assert np.array_equal(K, Ko)
+    q_init = np.array([0.8, 0.0, 0.6, 0.0])
+    r_init = np.array([0.5, -1.0, 2.0])
+    Q, R = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, n, qe, q_init, r_init)
+    B = rod.position_rhs(torch.from_numpy(Qo).cuda()).cpu().numpy()
+    Bo = np.stack([np.ascontiguousarray(oracle.position_rhs(np.asfortranarray(Qi.T)).T) for Qi in Qo])
+    assert np.array_equal(B, Bo)
+    relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
+    relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
+    assert relq <= 1e-12 and relr <= 1e-12, (relq, relr, rod.iterations)
+    assert np.abs(Q.cpu().numpy() - Qo).max() <= 5e-12
+
+
+def test_quaternion_rhs_kernel(sri):
+    import torch
+
+    rod = sri.RodIntegrator(16)
+    rng = np.random.default_rng(4)
+    K = rng.normal(size=(7, 3, 15)); Q = rng.normal(size=(7, 4, 15))
+    G = rod.quaternion_rhs(torch.from_numpy(K).cuda(), torch.from_numpy(Q).cuda()).cpu().numpy()
+    k0, k1, k2 = K[:, 0], K[:, 1], K[:, 2]
+    w, x, y, z = Q[:, 0], Q[:, 1], Q[:, 2], Q[:, 3]
+    ref = 0.5 * np.stack([-k0 * x - k1 * y - k2 * z, k0 * w + k2 * y - k1 * z, k1 * w - k2 * x + k0 * z, k2 * w + k1 * x - k0 * y], axis=1)
+    assert np.allclose(G, ref, rtol=0, atol=1e-15)
+
+
+def test_large_batch_properties(sri):
+    """N=256, 4096 rods: too many for the dense oracle — check invariants of the exact solution instead."""
+    import torch
+
+    n, rods = 256, 4096
+    rod = sri.RodIntegrator(n)
+    qe = torch.from_numpy(_qe_batch(rods, scale=1.0)).cuda()
+    Q, R = rod.integrate(qe)
+    torch.cuda.synchronize()
+    assert rod.last_update <= 1e-14 and rod.iterations <= 80
+    # Q' = 1/2 A(K) Q with skew A keeps |q| = 1 (spectral accuracy at N=256 is far below 1e-12 for these fields)
+    assert (Q.pow(2).sum(dim=1).sqrt() - 1).abs().max().item() <= 1e-11
+    # r' = R(q) e1 has unit speed: arc length of the rod = 1, so |r(tip)| <= 1
+    assert R[:, :, 0].norm(dim=1).max().item() <= 1.0 + 1e-12
+    # planar rods (only K_y != 0): closed form theta(X) = int K_y, q = (cos th/2, 0, sin th/2, 0)
+    qp = torch.zeros((8, 9), dtype=torch.float64, device="cuda")
+    qp[:, 3] = torch.linspace(-2, 2, 8, dtype=torch.float64, device="cuda")          # constant curvature K_y = c
+    Qp, Rp = rod.integrate(qp)
+    theta_tip = qp[:, 3]
+    assert (Qp[:, 0, 0] - torch.cos(theta_tip / 2)).abs().max().item() <= 1e-12
+    assert (Qp[:, 2, 0] - torch.sin(theta_tip / 2)).abs().max().item() <= 1e-12
+
+
+def test_not_converged_is_reported(sri):
+    import torch
+
+    rod = sri.RodIntegrator(16)
+    qe = torch.from_numpy(_qe_batch(3, scale=2.0)).cuda()
+    with pytest.raises(sri.SriError) as e:
+        rod.integrate_quaternions(qe, max_iter=2)
+    assert e.value.status == -7 and rod.iterations == 2 and rod.last_update > 1e-8

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""rod_bench.py — measurement of the widened rows: batched rod integration on one MI355X.
+
+Prints one JSON line: rods/s for quaternion + position integration of `--rods` rods with N nodes, the
+fixed-point iteration count, and a per-kernel breakdown.  The elementwise kernels are HBM-bound and are
+priced against the 8 TB/s HBM roofline with their algorithmic bytes (per rod and node: strain 3 doubles
+written; quaternion RHS 7 read + 4 written; position RHS 4 read + 3 written); the integration apply is
+the MFMA kernel of bench.py (8 (N-1)^2 flop per 4 columns)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri  # noqa: E402
+
+
+def timed(fn, reps=20):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--rods", type=int, default=65536)
+    ap.add_argument("--scale", type=float, default=2.0, help="qe ~ U[-scale, scale)")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    n, rods, m = args.n, args.rods, args.n - 1
+    dev = torch.device("cuda", 0)
+    rod = sri.RodIntegrator(n)
+    g = torch.Generator(device=dev).manual_seed(0x5EED)
+    qe = (torch.rand((rods, 9), dtype=torch.float64, device=dev, generator=g) * 2 - 1) * args.scale
+    # clock ramp
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        rod.integrate(qe)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        Q, R = rod.integrate(qe)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    iters = rod.iterations
+    # per-kernel breakdown
+    K = rod.strain_field(qe)
+    ms_strain = timed(lambda: rod.strain_field(qe))
+    ms_qrhs = timed(lambda: rod.quaternion_rhs(K, Q))
+    ms_prhs = timed(lambda: rod.position_rhs(Q))
+    integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+    G = rod.quaternion_rhs(K, Q)
+    xb = torch.zeros((rods, 4), dtype=torch.float64, device=dev)
+    out = torch.empty_like(G)
+    ms_apply4 = timed(lambda: integ.integrate(G, xb, out=out))
+    el = lambda cols_moved, ms: cols_moved * m * 8.0 * rods / (ms * 1e-3) / 1e9
+    res = {
+        "metric": "rods/s (quaternion + position integration, fp64)", "value": rods / best, "unit": "rods/s",
+        "n": n, "rods": rods, "qe_scale": args.scale, "ms_total": best * 1e3, "picard_iterations": iters,
+        "last_update": rod.last_update,
+        "unit_quaternion_defect_max": float((Q.pow(2).sum(dim=1).sqrt() - 1).abs().max()),
+        "breakdown_ms": {"strain_field": ms_strain, "quaternion_rhs": ms_qrhs, "position_rhs": ms_prhs,
+                         "integration_apply_4cols": ms_apply4},
+        "hbm_GBps": {"strain_field": el(3, ms_strain), "quaternion_rhs": el(11, ms_qrhs), "position_rhs": el(7, ms_prhs)},
+        "hbm_frac_of_8TBps": {"strain_field": el(3, ms_strain) / 8000, "quaternion_rhs": el(11, ms_qrhs) / 8000,
+                              "position_rhs": el(7, ms_prhs) / 8000},
+        "integration_apply_TFLOPs": 8.0 * m * m * rods / (ms_apply4 * 1e-3) / 1e12,
+        "model_ms": iters * (ms_qrhs + ms_apply4) + ms_strain + ms_prhs + ms_apply4 * 0.75,
+    }
+    # CPU baseline: the oracle's restatement of main.cpp (dense per-rod solve), single thread, bounded sample
+    try:
+        import oracle
+        qh = qe[:64].cpu().numpy()
+        t0 = time.perf_counter(); done = 0
+        for q in qh:
+            Qo = oracle.integrate_quaternions(n, q)
+            oracle.integrate_position(n, Qo)
+            done += 1
+            if time.perf_counter() - t0 > 8.0:
+                break
+        dt = time.perf_counter() - t0
+        Qo_all = Q[:1].cpu().numpy()[0]
+        err = float(np.abs(Qo_all - np.ascontiguousarray(oracle.integrate_quaternions(n, qh[0]).T)).max())
+        res["cpu_baseline"] = {"value": done / dt, "unit": "rods/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle dense per-rod solve (main.cpp:91-176), {done} rods at N={n}"}
+        res["max_abs_err_vs_oracle_rod0"] = err
+    except Exception as e:  # pragma: no cover
+        res["cpu_baseline"] = {"error": str(e)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
