@@ -143,13 +143,14 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           Otherwise X goes through registers with bounds checks and zero fill, Y by guarded
 //           8-byte stores: any rows / ld / M / alignment.
 //   RANK1 : epilogue subtracts w[row]*xb[col] (the initial-value term of main.cpp:162-164,172).
+//   TAIL  : rows % 16 != 0 (DMA builds): safe source addresses + LDS fix-up for the last k chunk of a tile.
 //   STAMP : diagnostic only — lane 0 of each workgroup records shader-clock / real-time stamps.
 //   ABL   : diagnostic only (tools/apply_diag.hip) — ablation mask, results are WRONG when non-zero:
 //           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
 //           4 = no Y stores, 8 = read LDS fragments only in the first stage,
 //           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts.
 // ---------------------------------------------------------------------------------------------
-template <class G, bool DMA, bool RANK1, bool STAMP = false, int ABL = 0>
+template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // piece position (lane & 7) of column 8i + (lane >> 3), which must hold source piece
   // (lane & 7) ^ sigma(column).
   const char* xsrc[DMA ? G::X_DMA_PER_WAVE : 1];
-  int xsafe[DMA ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
+  int xsafe[(DMA && TAIL) ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
   const char* asrc;
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
   size_t col0_i = 0;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // beyond the last row must not be fetched from where it "would be" (that is the next column, or past
         // the end of the buffer): it is fetched from the same piece of the PREVIOUS chunk instead (a full chunk
         // of the same column: rows >= 17 here) and its LDS image is rewritten by fixup_tail() before use.
-        xsafe[it] = (p.tail_k != 0 && 2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
+        if constexpr (TAIL) xsafe[it] = (2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
           const int i = wid + it * NW;
-          const int back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
+          int back = 0;
+          if constexpr (TAIL) back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
           lds_dma16(xsrc[it] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sX + i * 1024);
         }
       }
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       if (!(ABL & 2) || abl_first) {
         const int it = idx - G::A_DMA_PER_WAVE;
         const int i = wid + it * NW;
-        const int back = (kc_i + 1 == p.nk) ? xsafe[DMA ? it : 0] : 0;
+        int back = 0;
+        if constexpr (DMA && TAIL) back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
         lds_dma16(xsrc[DMA ? it : 0] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sA + G::A_BYTES + i * 1024);
       }
       if constexpr (ABL != 0) { if (idx == G::DMA_PER_WAVE - 1) abl_first = false; }
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       wait_stage_and_barrier<0>();                         // tail of the stream: fewer stages in flight
     }
     if (since_store < 99) ++since_store;
-    if constexpr (DMA) {
-      if (p.tail_k != 0 && kc_s + 1 == p.nk) fixup_tail(slot, tile_s);
+    if constexpr (DMA && TAIL) {
+      if (kc_s + 1 == p.nk) fixup_tail(slot, tile_s);
     }
     if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
   };
@@ -699,38 +702,40 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
 // Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
 // that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
 // inside a stream capture (HIP graph).
-template <class G, bool DMA, bool RANK1>
+template <class G, bool DMA, bool RANK1, bool TAIL>
 static int& residency(int dev) {
   static int blocks_per_cu[16] = {};
   return blocks_per_cu[dev];
 }
 
-template <class G, bool DMA, bool RANK1>
+template <class G, bool DMA, bool RANK1, bool TAIL>
 static int prepare(int dev) {
   if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1>(dev) != 0) return SRI_OK;
-  const auto kern = &apply_kernel<G, DMA, RANK1>;
+  if (residency<G, DMA, RANK1, TAIL>(dev) != 0) return SRI_OK;
+  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL>;
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
-  residency<G, DMA, RANK1>(dev) = nb < 1 ? 1 : nb;
+  residency<G, DMA, RANK1, TAIL>(dev) = nb < 1 ? 1 : nb;
   return SRI_OK;
 }
 
 template <class G>
 static int prepare_geometry(int dev) {
-  int rc = prepare<G, true, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true>(dev);
-  if (rc == SRI_OK) rc = prepare<G, false, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, false, true>(dev);
+  int rc = prepare<G, true, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
+  if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
   return rc;
 }
 
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
-template <class G, bool DMA, bool RANK1>
+template <class G, bool DMA, bool RANK1, bool TAIL>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream) {
-  const int per_cu = residency<G, DMA, RANK1>(dev);
+  const int per_cu = residency<G, DMA, RANK1, TAIL>(dev);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;
@@ -739,7 +744,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
+  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -749,10 +754,13 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
-  if (dma && rank1) return launch<G, true, true>(args, col_tiles, dev, cus, cap, stream);
-  if (dma) return launch<G, true, false>(args, col_tiles, dev, cus, cap, stream);
-  if (rank1) return launch<G, false, true>(args, col_tiles, dev, cus, cap, stream);
-  return launch<G, false, false>(args, col_tiles, dev, cus, cap, stream);
+  const bool tail = args.tail_k != 0;
+  if (dma && tail) return rank1 ? launch<G, true, true, true>(args, col_tiles, dev, cus, cap, stream)
+                                : launch<G, true, false, true>(args, col_tiles, dev, cus, cap, stream);
+  if (dma) return rank1 ? launch<G, true, true, false>(args, col_tiles, dev, cus, cap, stream)
+                        : launch<G, true, false, false>(args, col_tiles, dev, cus, cap, stream);
+  return rank1 ? launch<G, false, true, false>(args, col_tiles, dev, cus, cap, stream)
+               : launch<G, false, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
 static const char* kernel_name(int geo, bool dma) {

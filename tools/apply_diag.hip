@@ -22,7 +22,7 @@ using namespace sri;
 template <class G, bool DMA, bool STAMP, int ABL = 0>
 static float time_kernel(ApplyArgs a, size_t col_tiles, int reps, float* min_ms = nullptr) {
   a.col_tiles = (uint32_t)col_tiles;
-  auto kern = apply_kernel<G, DMA, false, STAMP, ABL>;
+  auto kern = apply_kernel<G, DMA, false, false, STAMP, ABL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int per_cu = 0;
@@ -46,7 +46,7 @@ static float time_kernel(ApplyArgs a, size_t col_tiles, int reps, float* min_ms 
 template <class G>
 static void occupancy(const char* name) {
   int nb = 0;
-  auto kern = apply_kernel<G, true, false, false>;
+  auto kern = apply_kernel<G, true, false, false, false>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
   hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
   if (h->geo != GEO_TALL) { printf("diag is written for the tall geometry (rows > 128)\n"); return 0; }
   const size_t col_tiles = (M + GeoTall::BN - 1) / GeoTall::BN;
   int tall_per_cu = 0;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&tall_per_cu, apply_kernel<GeoTall, true, false, false>, GeoTall::THREADS, GeoTall::LDS_BYTES));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&tall_per_cu, apply_kernel<GeoTall, true, false, false, false>, GeoTall::THREADS, GeoTall::LDS_BYTES));
   const size_t blocks = std::min<size_t>(col_tiles * a.row_blocks, (size_t)tall_per_cu * prop.multiProcessorCount);   // persistent grid
   const double flops = 2.0 * n * (double)n * M;
 
