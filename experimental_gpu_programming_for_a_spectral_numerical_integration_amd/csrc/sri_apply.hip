@@ -6,12 +6,12 @@
 // batched over rods: X holds one column per (rod, state component), column-major, so a column
 // is R contiguous doubles (main.cpp:113,130-133).
 //
-// Design (DESIGN.md has the numbers):
+// Design (DESIGN.md §4 has the measurements behind every choice):
 //   * v_mfma_f64_16x16x4_f64 does all the arithmetic.  Measured on MI355X (profiles/
 //     r01_mfma_f64_probe.log): one issue per 64 cycles per SIMD, same dependent latency,
 //     77.5 TF chip-wide; f64 VALU work shares that pipe, so the inner loop holds no f64 VALU.
 //   * A (up to 8 MiB at N=1024) does not fit a CU.  It is packed on the host ONCE, at handle
-//     creation, into the exact byte order the MFMA A-fragments are read in
+//     creation, into the exact byte order the MFMA fragments are read in
 //     ([row block][k chunk][16-row tile][k pair][lane][2]), so that a K-slab is one linear
 //     LDS-DMA copy (global_load_lds_dwordx4, no VGPRs) and every fragment read is a
 //     conflict-free 1-KiB ds_read_b128.  A stays resident in each XCD's 4 MiB L2; HBM sees it once.
@@ -19,15 +19,25 @@
 //     moves 8 columns x 128 contiguous bytes.  The LDS image keeps one 128-byte row per column
 //     with its eight 16-byte pieces XOR-swizzled by (column>>1)&7 — applied on the per-lane
 //     SOURCE address, because the LDS side of an LDS-DMA is lane-linear — which makes the
-//     B-fragment ds_read_b128 conflict-free (tools/lds_bank_model.py).
-//   * k is consumed in the order (k pair j, lane k-slot g, element e) -> 8j + 2g + e and the 16
-//     rows of every output tile are permuted (row_of_slot) so that each lane ends up with
-//     adjacent rows: Y leaves in 16-byte stores, four lanes covering one 64-byte segment.
-//     Both permutations are folded into the host-side packing of A; X and Y keep the caller's
-//     plain column-major layout.
-//   * 256-thread workgroups (one wave per SIMD), two workgroups per CU (<= 256 VGPRs,
-//     80 KiB LDS each) so that one workgroup's barrier / epilogue is covered by the other's
-//     MFMAs.  Two-stage LDS ring, one barrier per 16-deep k chunk.
+//     X-fragment ds_read_b128 conflict-free (tools/lds_bank_model.py; SQ_LDS_BANK_CONFLICT = 0).
+//   * The X fragment is the MFMA's first operand, i.e. every tile is accumulated TRANSPOSED: the 16
+//     lanes of a quarter-wave hold 16 rows of one column, and interleaving the rows of two stacked
+//     tiles (row_of_slot) gives each lane two adjacent rows, so Y leaves in 16-byte stores that
+//     are 256 contiguous bytes per quarter-wave.  k is consumed in the order (k pair j, lane
+//     k-slot g, element e) -> 8j + 2g + e.  Both permutations are folded into the host-side
+//     packing of A; X and Y keep the caller's plain column-major layout.
+//   * PERSISTENT: one 512-thread workgroup per CU (256 x 128 tile, 2 waves per SIMD, 144 KiB LDS
+//     ring of 3 stages, 2 in flight) walks tiles b, b+grid, ...; the (tile, k chunk) pairs form one
+//     stream that keeps flowing across tile boundaries.  Stages are awaited with counted
+//     s_waitcnt vmcnt(N) + raw s_barrier (never __syncthreads(), whose fence drains vmcnt), so that
+//     the previous tile's Y stores may stay in flight for two stages.
+//   * The LDS-DMA pieces of a refill are dropped one by one behind MFMA groups (a piece costs the
+//     issuing wave 60-180 cycles), and the two wave groups of a workgroup run the stream SHIFTED
+//     by most of a k pair against the shared barriers: after a barrier the late group still owns
+//     MFMAs with operands in registers, and each group's stores are issued while the other computes.
+//   * Any fp64 panel qualifies: 8-byte alignment is enough for LDS-DMA and 16-byte stores
+//     (tools/unaligned_probe.hip); rows % 16 != 0 (every integration operator: N-1 rows) is handled by
+//     safe source addresses + an LDS fix-up of the last k chunk (template parameter TAIL).
 //
 // There is no CPU fallback: without a gfx950 device every entry point fails with an error.
 #include <hip/hip_runtime.h>
