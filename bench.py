@@ -101,6 +101,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # SRI_BENCH_REHEARSAL=1: rehearse N > 1 on a ONE-GPU box — every rank uses cuda:0 and the collectives are
+    # staged through CPU tensors over gloo (RCCL refuses two ranks on one device).  Timings are meaningless
+    # there; the point is to run the rank / world-size logic for real.
+    rehearsal = os.environ.get("SRI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -113,7 +119,26 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def all_gather(out, inp):
+        if rehearsal:
+            tmp = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(tmp, inp.cpu())
+            out.copy_(tmp)
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
+    def all_reduce_max(t):
+        if rehearsal:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
     from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel
@@ -156,10 +181,10 @@ def main():
             ready[b].record()
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready[b])
-                dist.all_gather_into_tensor(tips_all[b], tips_local[b])
+                all_gather(tips_all[b], tips_local[b])
                 gathered[b].record()
         elif use_dist and args.gather == "full":
-            dist.all_gather_into_tensor(full_all, Y)
+            all_gather(full_all, Y)
 
     def fence():
         torch.cuda.synchronize()
@@ -183,30 +208,30 @@ def main():
         step(i, events[i])
     if use_dist and args.gather == "final":
         # reassemble the final integrated state of the whole job: one RCCL all-gather over xGMI
-        dist.all_gather_into_tensor(tips_all[(args.steps - 1) & 1], tips_local[(args.steps - 1) & 1])
+        all_gather(tips_all[(args.steps - 1) & 1], tips_local[(args.steps - 1) & 1])
     fence()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_max(t)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
     # optional: one full-panel all-gather timed on its own (reported, never part of `value`)
     full_gather_ms = None
     tip_gather_ms = None
     if use_dist and args.gather in ("tip", "final"):
-        dist.all_gather_into_tensor(tips_all[0], tips_local[0]); fence()
+        all_gather(tips_all[0], tips_local[0]); fence()
         t1 = time.perf_counter()
         for _ in range(10):
-            dist.all_gather_into_tensor(tips_all[0], tips_local[0])
+            all_gather(tips_all[0], tips_local[0])
         fence()
         tip_gather_ms = (time.perf_counter() - t1) * 1e3 / 10
         try:
             buf = torch.empty((M * world, rows), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(buf, Y); fence()
-            t1 = time.perf_counter(); dist.all_gather_into_tensor(buf, Y); fence()
+            all_gather(buf, Y); fence()
+            t1 = time.perf_counter(); all_gather(buf, Y); fence()
             full_gather_ms = (time.perf_counter() - t1) * 1e3
             del buf
         except Exception:
@@ -222,6 +247,15 @@ def main():
         Yr = oracle.apply(A, Xs, threads=0)
         verify = float(np.linalg.norm(Ys - Yr) / np.linalg.norm(Yr))
 
+    gather_ok = None
+    if use_dist and args.gather in ("tip", "final"):
+        # every rank's slab of the gathered state must equal that rank's own tips (checked on every rank, reduced)
+        b_last = (args.steps - 1) & 1
+        mine = tips_all[b_last][rank * M:(rank + 1) * M]
+        ok = torch.tensor([1.0 if torch.equal(mine, Y[:, 0].contiguous()) else 0.0], dtype=torch.float64, device=dev)
+        neg = -ok
+        all_reduce_max(neg)                                 # max of negatives = -(min of ok)
+        gather_ok = bool(-neg.item() == 1.0)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rods * world / (elapsed / args.steps)
@@ -261,6 +295,8 @@ def main():
             out["full_panel_allgather_ms"] = full_gather_ms
         if tip_gather_ms is not None:
             out["tip_state_allgather_ms"] = tip_gather_ms
+        if gather_ok is not None:
+            out["gathered_state_verified"] = gather_ok
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         sys.stdout.flush()
