@@ -537,10 +537,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
   };
   // Y stores of `tile` + accumulators back to zero
-  auto finish_tile = [&](uint32_t tile) __attribute__((always_inline)) {
+  // `since_value`: 0 if the stores follow this body's DMA pieces in program order (the next TWO waits have them
+  // behind the awaited stage), 1 if they precede them (only the next wait does).
+  auto finish_tile = [&](uint32_t tile, uint32_t since_value) __attribute__((always_inline)) {
     if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
     if (store_tile(tile)) {
-      since_store = 0;
+      since_store = since_value;
     } else {
       if constexpr ((ABL & 4) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // edge tile: unknown store count, drain
       since_store = 99;
@@ -566,13 +568,30 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   const uint32_t steady_end = total_stages > static_cast<uint32_t>(AHEAD) ? total_stages - AHEAD : 0;
 
+  // STAMP builds: cycles per body segment, summed over the steady bodies (s_memtime drains lgkmcnt, so the
+  // numbers are shares, not the product kernel's run time).
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long seg_t = 0;
+  auto seg_start = [&]() __attribute__((always_inline)) { if constexpr (STAMP) seg_t = __builtin_amdgcn_s_memtime(); };
+  auto seg_mark = [&](int k) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      seg[k] += now - seg_t;
+      seg_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   if (!late) {
     // ---------------- early group (or the whole workgroup when STAGGER is off) ----------------------
     auto body = [&](auto refill_tag) __attribute__((always_inline)) {
       constexpr bool REFILL = decltype(refill_tag)::value;
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
+      seg_start();
       wait_stage(refill_tag, slot_c, kc_c, tile_c);
+      seg_mark(0);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
@@ -581,14 +600,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       read_pair(slot_c, 1, qa, qb);
       if constexpr ((ABL & 8) != 0) abl_read = false;
       mfma_groups(pa, pb, I2{}, IG{}, piece, PT{});
+      seg_mark(1);
       mfma_groups(qa, qb, I0{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
+      seg_mark(2);
       if constexpr (REFILL) {
         stage_commit(rslot);
         cursor_advance();
       }
       const uint32_t done_tile = tile_c;
-      if (advance_compute()) finish_tile(done_tile);
+      if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); } else seg_mark(3);
     };
     uint32_t s = 0;
     for (; s < steady_end; ++s) body(std::true_type{});
@@ -622,24 +643,31 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
       int piece = 0;
+      seg_start();
       mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
       const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
       const bool wraps = kc_c + 1 == p.nk;                           // stage s opens the next tile
       wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + gridDim.x : tile_c);
+      seg_mark(0);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
       read_pair(next_slot, 0, pa, pb);                               // (s, 0): landed, consumed 7 groups later
       mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
+      seg_mark(1);
       const uint32_t done_tile = tile_c;
-      if (advance_compute()) finish_tile(done_tile);                 // now slot_c names stage s
+      // (Issuing the late group's DMA pieces half a stage later, out of phase with the early group's, was
+      // measured: no gain.)  The stores follow this body's pieces in program order.
+      if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
       read_pair(slot_c, 1, qa, qb);                                  // (s, 1): used at the top of the next body
       mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      seg_mark(2);
       if constexpr (REFILL) {
         stage_commit(rslot);
         cursor_advance();
       }
+      seg_mark(3);
     };
     uint32_t s = 0;
     if (steady_end > 0) first_body(std::true_type{}); else first_body(std::false_type{});
@@ -650,7 +678,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       int piece = 0;
       mfma_groups(qa, qb, I0{}, IG{}, piece, std::false_type{});
       const uint32_t done_tile = tile_c;
-      if (advance_compute()) finish_tile(done_tile);
+      if (advance_compute()) finish_tile(done_tile, 0u);
     }
   }
 
@@ -662,6 +690,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime();
       o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
       o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+    }
+    // per-segment sums of wave 0 (early group) and wave NW/2 (late group): 2 x 8 words behind the per-WG block
+    if (lane == 0 && (wid == 0 || wid == NW / 2)) {
+      unsigned long long* q = p.stamps + static_cast<size_t>(gridDim.x) * 8 + (static_cast<size_t>(blockIdx.x) * 2 + (wid ? 1 : 0)) * 8;
+      for (int k = 0; k < 6; ++k) q[k] = seg[k];
+      q[6] = total_stages;
+      q[7] = my_tiles;
     }
   }
 }

@@ -111,8 +111,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dX, hx.data(), sizeof(double) * n * M, hipMemcpyHostToDevice));
 
   // STAMP run
-  CK(hipMalloc(&dS, sizeof(unsigned long long) * 8 * blocks));
-  CK(hipMemset(dS, 0, sizeof(unsigned long long) * 8 * blocks));
+  CK(hipMalloc(&dS, sizeof(unsigned long long) * 24 * blocks));
+  CK(hipMemset(dS, 0, sizeof(unsigned long long) * 24 * blocks));
   a.stamps = dS;
   ms = time_kernel<GeoTall, true, true>(a, col_tiles, 5, &mn);
   printf("stamped  : mean %.4f ms (min %.4f)\n", ms, mn);
@@ -151,6 +151,26 @@ int main(int argc, char** argv) {
   printf("WG start times (us): #0 %.1f  #255 %.1f  #511 %.1f  #512 %.1f  #1023 %.1f  #1024 %.1f  #2048 %.1f  last %.1f\n",
          starts[0], starts[std::min<size_t>(255, blocks - 1)], starts[std::min<size_t>(511, blocks - 1)], starts[std::min<size_t>(512, blocks - 1)],
          starts[std::min<size_t>(1023, blocks - 1)], starts[std::min<size_t>(1024, blocks - 1)], starts[std::min<size_t>(2048, blocks - 1)], starts.back());
+  // ---- per-segment cycle shares of one early and one late wave per workgroup ------------------------
+  {
+    std::vector<unsigned long long> sg(24 * blocks);
+    CK(hipMemcpy(sg.data(), dS, sizeof(unsigned long long) * 24 * blocks, hipMemcpyDeviceToHost));
+    const char* names_e[5] = {"wait+barrier", "k pair 0 (+ read pair 1, DMA pieces)", "k pair 1", "bookkeeping", "tile end (stores, zero)"};
+    const char* names_l[5] = {"group 0 + wait+barrier", "rest of prev k pair 1 (+ DMA pieces)", "k pair 0 (+ read pair 1)", "bookkeeping", "tile end (stores, zero)"};
+    for (int grp = 0; grp < 2; ++grp) {
+      double tot[6] = {0, 0, 0, 0, 0, 0}, stages = 0;
+      for (size_t b = 0; b < blocks; ++b) {
+        const unsigned long long* q = &sg[8 * blocks + (b * 2 + grp) * 8];
+        for (int k = 0; k < 6; ++k) tot[k] += (double)q[k];
+        stages += (double)q[6];
+      }
+      double all = 0; for (int k = 0; k < 5; ++k) all += tot[k];
+      printf("%s wave, cycles per stage (stamped build; ideal 2 waves/SIMD = %d):", grp ? "late " : "early", 64 * 64 * 2);
+      for (int k = 0; k < 5; ++k) printf("  %s %.0f", grp ? names_l[k] : names_e[k], tot[k] / stages);
+      printf("  | total %.0f\n", all / stages);
+    }
+  }
+
   // ---- ablations (results wrong by construction; timing + clock only) --------------------------
   ablate<0>("none (stamped product kernel)", a, col_tiles, blocks, flops, dS);
   ablate<1>("no A re-fetch (L2->LDS)", a, col_tiles, blocks, flops, dS);
