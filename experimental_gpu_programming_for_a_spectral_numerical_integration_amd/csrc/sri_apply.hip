@@ -704,7 +704,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 // ---------------------------------------------------------------------------------------------
 // Handle
 // ---------------------------------------------------------------------------------------------
+#ifndef SRI_TALL_WAVES
+#define SRI_TALL_WAVES 8             // experiment knob: 16 = four waves per SIMD with 64x32 wave tiles
+#endif
+#if SRI_TALL_WAVES == 16
+using GeoTall = Geo<4, 4, 4, 2, 3>;   // BM 256 x BN 128, 16 waves (64x32 each), 144 KiB ring, 1 WG/CU
+#else
 using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...)
+#endif
 using GeoMid = Geo<2, 2, 4, 2, 3>;    // BM 128 x BN  64, 4 waves,  72 KiB ring, 2 WG/CU : 64 < rows <= 128
 using GeoFlat = Geo<1, 4, 4, 1, 3>;   // BM  64 x BN  64, 4 waves,  48 KiB ring, 3 WG/CU : rows <= 64 (N = 16, 64)
 
