@@ -8,14 +8,18 @@
 //
 // The strain coordinates are the hard-coded qe of main.cpp:187-195.  With `rods > 1` the same rod is
 // replicated with a per-rod scaling of qe so that the batched device path is exercised.
-// Output mirrors main.cpp:198,202 ("Q_stack : " / "r_stack : "); `--full` prints 17 significant digits.
+// Output mirrors main.cpp:198,202: "Q_stack : \n" << Q_stack << std::endl with Eigen's default IOFormat
+// (stream precision 6, every coefficient right-aligned to the widest one, columns separated by one space);
+// `--full` prints 17 significant digits, one value / row per line, for tests.
 //
 // Build (see tests/test_examples_gpu.py):
 //   g++ -std=c++17 -O2 -Iinclude examples/rod_main.cpp -L<pkg> -lsri_hip -Wl,-rpath,<pkg> -o build/rod_main
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "chebyshev_differentiation.h"
@@ -95,6 +99,28 @@ static void updatePositionb(const std::vector<double>& Q, double* b /* M1 x 3 co
   }
 }
 
+// What `std::cout << M` prints for an Eigen matrix with the default IOFormat: "%.6g"-style coefficients,
+// all padded on the left to the width of the widest, " " between columns, "\n" between rows.
+static void print_like_eigen(const double* a, unsigned rows, unsigned cols, unsigned ld) {
+  std::vector<std::string> txt(static_cast<size_t>(rows) * cols);
+  size_t width = 0;
+  char buf[64];
+  for (unsigned j = 0; j < cols; ++j)
+    for (unsigned i = 0; i < rows; ++i) {
+      std::snprintf(buf, sizeof buf, "%.6g", a[i + static_cast<size_t>(j) * ld]);
+      txt[i + static_cast<size_t>(j) * rows] = buf;
+      width = std::max(width, txt[i + static_cast<size_t>(j) * rows].size());
+    }
+  for (unsigned i = 0; i < rows; ++i) {
+    for (unsigned j = 0; j < cols; ++j) {
+      if (j) std::printf(" ");
+      std::printf("%*s", static_cast<int>(width), txt[i + static_cast<size_t>(j) * rows].c_str());
+    }
+    if (i + 1 < rows) std::printf("\n");
+  }
+  std::printf("\n");                                    // std::endl of main.cpp:198,202
+}
+
 int main(int argc, char* argv[]) {
   unsigned rods = 1;
   bool full = false;
@@ -114,7 +140,8 @@ int main(int argc, char* argv[]) {
       Q[r] = integrateQuaternions(qe);
     }
     std::printf("Q_stack : \n");
-    for (unsigned k = 0; k < state_dimension * M1; ++k) std::printf(full ? "%.17g\n" : "%.6g\n", Q[0][k]);
+    if (full) for (unsigned k = 0; k < state_dimension * M1; ++k) std::printf("%.17g\n", Q[0][k]);
+    else print_like_eigen(Q[0].data(), state_dimension * M1, 1, state_dimension * M1);
 
     // ---- positions: one batched device product for all rods (the hot path) ------------------------
     const size_t cols = static_cast<size_t>(rods) * 3;
@@ -123,8 +150,8 @@ int main(int argc, char* argv[]) {
     sri::SpectralApply integrate(number_of_Chebyshev_points, SRI_OP_DNN_INV, 0);
     sri::check(sri_integrate_host(integrate.handle(), B.data(), M1, r_init.data(), R.data(), M1, cols), "sri_integrate_host");
     std::printf("r_stack : \n");
-    for (unsigned i = 0; i < M1; ++i)
-      std::printf(full ? "%.17g %.17g %.17g\n" : "%.6g %.6g %.6g\n", R[i], R[i + M1], R[i + 2 * M1]);
+    if (full) for (unsigned i = 0; i < M1; ++i) std::printf("%.17g %.17g %.17g\n", R[i], R[i + M1], R[i + 2 * M1]);
+    else print_like_eigen(R.data(), M1, 3, M1);
     if (rods > 1) std::printf("(rod 0 of %u shown; kernel %s)\n", rods, sri_apply_last_kernel(integrate.handle()));
   } catch (const std::exception& e) {
     std::fprintf(stderr, "rod_main: %s\n", e.what());
