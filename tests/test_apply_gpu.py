@@ -89,7 +89,7 @@ def test_mfma_layout_exact_integers(sri):
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
     Asymmetric data, as cdna_hip_programming.md §3 asks."""
     rng = np.random.default_rng(7)
-    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130)]:
+    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
@@ -298,6 +298,33 @@ def test_full_config3_n256(sri, oracle):
 
 def test_full_config5_n1024(sri, oracle):
     _full_size_checks(sri, oracle, 1024, 8192)
+
+
+def test_panel_beyond_4_gib(sri, oracle):
+    """2.4 M columns at N=256: X and Y are 4.9 GB each, so byte offsets exceed 32 bits; check columns at both
+    ends and across the 4 GiB line against the oracle."""
+    import torch
+
+    n, M = 256, 2_400_000 + 37                       # ragged tail on purpose
+    op = sri.SpectralApply(n, 0)
+    X = torch.empty((M, n), dtype=torch.float64, device="cuda")
+    chunk = 200_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for a in range(0, M, chunk):                      # fill in chunks: torch.rand temporaries stay small
+        b = min(a + chunk, M)
+        X[a:b] = torch.rand((b - a, n), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    Y = op.apply(X)
+    line = (4 << 30) // (n * 8)                       # first column whose bytes start beyond 4 GiB
+    idx = np.unique(np.concatenate([np.arange(0, 130), np.arange(line - 70, line + 70), np.arange(M - 200, M),
+                                    np.random.default_rng(1).integers(0, M, size=300)]))
+    ti = torch.from_numpy(idx).cuda()
+    A = oracle.dn(n)
+    Xs = np.asfortranarray(X[ti].cpu().numpy().T)
+    Ys = np.asfortranarray(Y[ti].cpu().numpy().T)
+    fro, back = parity_metrics(A, Xs, Ys, oracle.apply(A, Xs, threads=0))
+    assert fro <= FRO_TOL and back <= backward_tol(n), (fro, back)
+    del X, Y
+    torch.cuda.empty_cache()
 
 
 def test_differentiate_then_integrate_roundtrip(sri, oracle):
