@@ -158,7 +158,8 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //   ABL   : diagnostic only (tools/apply_diag.hip) — ablation mask, results are WRONG when non-zero:
 //           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
 //           4 = no Y stores, 8 = read LDS fragments only in the first stage,
-//           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts.
+//           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts,
+//           32 = the early wave group stores nothing, 64 = the late wave group stores nothing.
 // ---------------------------------------------------------------------------------------------
 template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     // what the counted waits of the stage stream rely on.
     const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
     const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
-    if constexpr ((ABL & 4) != 0) {
+    if ((ABL & 4) != 0 || ((ABL & 32) != 0 && wid < NW / 2) || ((ABL & 64) != 0 && wid >= NW / 2)) {
       // ablation: keep the accumulators live, store nothing
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
