@@ -300,6 +300,26 @@ def test_full_config5_n1024(sri, oracle):
     _full_size_checks(sri, oracle, 1024, 8192)
 
 
+@pytest.mark.parametrize("n,which,M", [(256, 0, 20000), (256, 1, 9001), (1024, 0, 2000), (64, 0, 50000), (128, 0, 7000)])
+def test_repeated_launches_are_bit_identical(sri, n, which, M):
+    """The kernel synchronises its LDS ring by hand (counted vmcnt + raw barriers, shifted wave groups): a
+    race or a read of a not-yet-landed stage would show up as run-to-run differences.  Thirty launches of the
+    same apply, interleaved with an unrelated memory-heavy kernel, must agree bit for bit."""
+    import torch
+
+    op = sri.SpectralApply(n, which)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.rand((M, op.rows), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    ref = op.apply(X).clone()
+    noise = torch.rand((1 << 24,), dtype=torch.float64, device="cuda")
+    for i in range(30):
+        if i % 3 == 0:
+            noise.mul_(1.0000001)                      # evict caches / perturb timing between launches
+        Y = op.apply(X)
+        assert torch.equal(Y, ref), i
+    torch.cuda.synchronize()
+
+
 def test_panel_beyond_4_gib(sri, oracle):
     """2.4 M columns at N=256: X and Y are 4.9 GB each, so byte offsets exceed 32 bits; check columns at both
     ends and across the 4 GiB line against the oracle."""
