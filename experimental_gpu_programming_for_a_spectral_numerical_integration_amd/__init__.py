@@ -56,6 +56,7 @@ C_ABI = {
     "sri_rod_destroy": (_int, [_vp]),
     "sri_rod_strain_field": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
     "sri_rod_integrate_positions": (_int, [_vp, _vp, _sz, _sz, _dp, _vp, _sz, _vp]),
@@ -340,6 +341,15 @@ class RodIntegrator:
         _chk(load_library().sri_rod_quaternion_rhs(self._h, K.data_ptr(), self.m, Q.data_ptr(), self.m, Q.shape[0],
                                                    G.data_ptr(), self.m, self._stream(Q)), "sri_rod_quaternion_rhs")
         return G
+
+    def quaternion_step(self, qe, G, q_base, tips=None):
+        """One fused Picard iteration (sri_rod_quaternion_step): returns G_next = 1/2 A(K) (Dnn^-1 G - w q_base^T)."""
+        import torch
+        Gn = torch.empty_like(G)
+        _chk(load_library().sri_rod_quaternion_step(self._h, qe.data_ptr(), G.data_ptr(), self.m, q_base.data_ptr(), G.shape[0],
+                                                    Gn.data_ptr(), self.m, tips.data_ptr() if tips is not None else None,
+                                                    self._stream(G)), "sri_rod_quaternion_step")
+        return Gn
 
     def position_rhs(self, Q):
         import torch

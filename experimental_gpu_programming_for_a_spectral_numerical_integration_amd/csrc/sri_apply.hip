@@ -109,6 +109,9 @@ struct ApplyArgs {
   const double* w;       // optional rank-1 epilogue: y -= w[row] * xb[col]   (w padded to row_blocks*BM)
   const double* xb;
   double* tips;          // optional: tips[col] = Y[0][col], the rod-tip node (chebyshev_differentiation.h:26: x_0 = L)
+  const double* qe;      // EPI_QUAT only: strain coefficients, 9 per rod (main.cpp:17, 187-195)
+  const double* leg1;    // EPI_QUAT only: P1, P2 of utilities.h:54-59 at the node of every (padded) row
+  const double* leg2;
   size_t ldx, ldy, m;    // m = number of columns
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
@@ -160,9 +163,19 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           4 = no Y stores, 8 = read LDS fragments only in the first stage,
 //           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts,
 //           32 = the early wave group stores nothing, 64 = the late wave group stores nothing.
+//   EPI   : EPI_QUAT fuses the caller on the far side of the product into the store stage:
+//           the panel is 4 columns (w, x, y, z) per rod, Q = A X - w xb^T is the new quaternion iterate, and what
+//           is stored is the NEXT right-hand side G = 1/2 A(K) Q of main.cpp:71-84 with K = Phi(X_row) qe
+//           (utilities.h:49-67, main.cpp:69) formed in registers — one Picard iteration of the rod pipeline per
+//           launch, no K or Q panel in HBM.  The MFMA column index of a 16-column tile is permuted
+//           (t -> 4*(t&3) + (t>>2), applied to the X-fragment read address only) so that the four accumulator
+//           registers of a lane are the four components of ONE rod at one node; stores keep their shape.
 // ---------------------------------------------------------------------------------------------
-template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0>
+enum { EPI_NONE = 0, EPI_QUAT = 1 };
+
+template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
+  static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
@@ -310,8 +323,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
-  const int sig = (c >> 1) & 7;
-  const int x_off = G::A_BYTES + (wn * TN * 16 + c) * X_ROW_BYTES;
+  // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
+  const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
+  const int sig = (cs >> 1) & 7;
+  const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
 
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
   // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
@@ -381,7 +396,70 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         }
       }
   };
+  // EPI_QUAT: acc[tm][tn][r] = (A X)[row_base + 32*(tm>>1) + (tm&1)][col_base4 + 16*tn + r], r = w, x, y, z of the rod
+  // in columns col_base4 + 16*tn .. +3.  Same store count and shape as the plain epilogue (the counted waits rely on it).
+  // Operation order of K and G is that of strain_kernel / quat_rhs_kernel (sri_rod.hip), so the fused iteration is
+  // bit-identical to the unfused one.
+  auto store_tile_quat = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    const uint32_t rb_c = tile / p.col_tiles;
+    const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
+    const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
+    const size_t col_base4 = col0_c + wn * (TN * 16) + 4 * g;
+    const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
+    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
+    const bool tip_lane = p.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const size_t col = col_base4 + tn * 16;
+      if (!full && col >= p.m) continue;                       // m is a multiple of 4: a rod is in or out as a whole
+      const double* qe = p.qe + (col >> 2) * 9;
+      double q9[9], xb[4];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q9[i] = qe[i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[r] = p.xb[col + r];
+#pragma unroll
+      for (int t = 0; t < TM / 2; ++t) {
+        const uint32_t row = row_base + 32 * t;
+        double gq[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double wv = p.w[row + e], P1 = p.leg1[row + e], P2 = p.leg2[row + e];   // tables are zero padded
+          const double qw = acc[2 * t + e][tn][0] - wv * xb[0], qx = acc[2 * t + e][tn][1] - wv * xb[1];
+          const double qy = acc[2 * t + e][tn][2] - wv * xb[2], qz = acc[2 * t + e][tn][3] - wv * xb[3];
+          if (tip_lane && t == 0 && e == 0) {
+            p.tips[col + 0] = qw; p.tips[col + 1] = qx; p.tips[col + 2] = qy; p.tips[col + 3] = qz;
+          }
+          double k[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double s = 0.0;
+            s = s + 1.0 * q9[a * 3 + 0];
+            s = s + P1 * q9[a * 3 + 1];
+            s = s + P2 * q9[a * 3 + 2];
+            k[a] = s;
+          }
+          gq[e][0] = 0.5 * (((0.0 - k[0] * qx) - k[1] * qy) - k[2] * qz);
+          gq[e][1] = 0.5 * ((k[0] * qw + k[2] * qy) - k[1] * qz);
+          gq[e][2] = 0.5 * ((k[1] * qw - k[2] * qx) + k[0] * qz);
+          gq[e][3] = 0.5 * ((k[2] * qw + k[1] * qx) - k[0] * qy);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double* yp = p.y + (col + r) * p.ldy + row;
+          if (full ? (all_rows || row + 1 < p.rows) : (DMA && row + 1 < p.rows)) {
+            *reinterpret_cast<d2*>(yp) = d2{gq[0][r], gq[1][r]};
+          } else {
+            if (row < p.rows) yp[0] = gq[0][r];
+            if (!full && row + 1 < p.rows) yp[1] = gq[1][r];
+          }
+        }
+      }
+    }
+    return full;
+  };
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
     const uint32_t rb_c = tile / p.col_tiles;
     const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
@@ -755,21 +833,21 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
 // Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
 // that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
 // inside a stream capture (HIP graph).
-template <class G, bool DMA, bool RANK1, bool TAIL>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
 static int& residency(int dev) {
   static int blocks_per_cu[16] = {};
   return blocks_per_cu[dev];
 }
 
-template <class G, bool DMA, bool RANK1, bool TAIL>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
 static int prepare(int dev) {
   if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1, TAIL>(dev) != 0) return SRI_OK;
-  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL>;
+  if (residency<G, DMA, RANK1, TAIL, EPI>(dev) != 0) return SRI_OK;
+  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>;
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
-  residency<G, DMA, RANK1, TAIL>(dev) = nb < 1 ? 1 : nb;
+  residency<G, DMA, RANK1, TAIL, EPI>(dev) = nb < 1 ? 1 : nb;
   return SRI_OK;
 }
 
@@ -781,14 +859,17 @@ static int prepare_geometry(int dev) {
   if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT>(dev);
+  if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT>(dev);
   return rc;
 }
 
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
-template <class G, bool DMA, bool RANK1, bool TAIL>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream) {
-  const int per_cu = residency<G, DMA, RANK1, TAIL>(dev);
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI>(dev);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;
@@ -797,7 +878,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
+  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -808,6 +889,11 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0;
+  if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
+    if (dma && tail) return launch<G, true, true, true, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
+    if (dma) return launch<G, true, true, false, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
+    return launch<G, false, true, false, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
+  }
   if (dma && tail) return rank1 ? launch<G, true, true, true>(args, col_tiles, dev, cus, cap, stream)
                                 : launch<G, true, false, true>(args, col_tiles, dev, cus, cap, stream);
   if (dma) return rank1 ? launch<G, true, true, false>(args, col_tiles, dev, cus, cap, stream)
@@ -816,12 +902,15 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
                : launch<G, false, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
-static const char* kernel_name(int geo, bool dma) {
-  static const char* names[3][2] = {
-      {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>"},
-      {"sri_apply_mfma_f64<128x64,reg>", "sri_apply_mfma_f64<128x64,dma>"},
-      {"sri_apply_mfma_f64<256x128,reg>", "sri_apply_mfma_f64<256x128,dma>"}};
-  return names[geo][dma ? 1 : 0];
+static const char* kernel_name(int geo, bool dma, bool quat = false) {
+  static const char* names[3][4] = {
+      {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<64x64,reg,quat>",
+       "sri_apply_mfma_f64<64x64,dma,quat>"},
+      {"sri_apply_mfma_f64<128x64,reg>", "sri_apply_mfma_f64<128x64,dma>", "sri_apply_mfma_f64<128x64,reg,quat>",
+       "sri_apply_mfma_f64<128x64,dma,quat>"},
+      {"sri_apply_mfma_f64<256x128,reg>", "sri_apply_mfma_f64<256x128,dma>", "sri_apply_mfma_f64<256x128,reg,quat>",
+       "sri_apply_mfma_f64<256x128,dma,quat>"}};
+  return names[geo][(dma ? 1 : 0) + (quat ? 2 : 0)];
 }
 
 struct DeviceGuard {
@@ -914,11 +1003,13 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
 }
 
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
-               hipStream_t stream, double* d_tips = nullptr) {
+               hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr) {
   if (h == nullptr || (M > 0 && (dX == nullptr || dY == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
   if (M == 0) return SRI_OK;
   const bool rank1 = d_xb != nullptr;
   if (rank1 && h->d_w == nullptr) return SRI_EINVAL;
+  if (quat != nullptr && (!rank1 || M % 4 != 0 || quat->qe == nullptr || quat->leg1 == nullptr || quat->leg2 == nullptr))
+    return SRI_EINVAL;
   DeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
@@ -930,6 +1021,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.w = h->d_w;
   args.xb = d_xb;
   args.tips = d_tips;
+  args.qe = quat ? quat->qe : nullptr;
+  args.leg1 = quat ? quat->leg1 : nullptr;
+  args.leg2 = quat ? quat->leg2 : nullptr;
   args.ldx = ldx;
   args.ldy = ldy;
   args.m = M;
@@ -945,11 +1039,19 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // the register-staged build.
   const bool dma = h->rows >= 16;
   args.tail_k = h->rows % 16;
-  h->last_kernel = kernel_name(h->geo, dma);
+  h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream);
   return dispatch<GeoTall>(h, args, dma, rank1, stream);
 }
+
+int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
+                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream) {
+  if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
+  return run(h, dG, ldg, dG_next, ldn, M, d_x_base, static_cast<hipStream_t>(stream), d_tips, &quat);
+}
+
+uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 0; }
 
 }  // namespace sri
 

@@ -21,6 +21,19 @@ int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double*
 // ---- error bookkeeping (sri_apply.hip): what sri_last_hip_error() reports -----------------------
 void record_hip_error(int hip_error);
 
+// ---- fused Picard iteration of the quaternion system (sri_apply.hip, used by sri_rod.hip) ----------
+// G_next = 1/2 A(K) (Dn_NN^-1 G - (Dn_NN^-1 Dn_IN) x_base^T),  K = Phi(X_row) qe, in ONE launch of the integration
+// apply: the right-hand side of main.cpp:71-84 is formed in the store stage from the accumulators.  All pointers are
+// device pointers; leg1/leg2 hold P1/P2 of utilities.h:54-59 per row, zero padded to padded_rows(h).
+struct QuatEpilogue {
+  const double* qe;     // 9 per rod
+  const double* leg1;
+  const double* leg2;
+};
+int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
+                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream);
+uint32_t padded_rows(const sri_apply_t* h);
+
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------
 // One v_mfma_f64_16x16x4_f64 computes D[i][j] += sum_k P[i][k] Q[k][j] (i, j < 16, k < 4); lane l feeds
 // P[l & 15][l >> 4] and Q[l >> 4][l & 15] and receives D[(l >> 4) + 4*reg][l & 15], reg = 0..3.

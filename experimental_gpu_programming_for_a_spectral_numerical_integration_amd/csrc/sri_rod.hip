@@ -15,6 +15,10 @@
 // O(N^2) work and converges to the solution of the reference's system to rounding (the iteration count and
 // the last update are returned; tests compare with the oracle's direct solve).
 //
+// One Picard iteration is ONE launch: the integration apply forms the next right-hand side 1/2 A(K) Q in its store
+// stage (EPI_QUAT of sri_apply.hip, K evaluated from qe in registers), so the loop streams a single 4-column panel
+// per rod in and out per iteration; the K and Q panels only exist at the start and the end.
+//
 // Panels are column-major with m = N-1 rows: per rod 3 columns of K, 4 of Q (w, x, y, z), 3 of b / r.
 // All elementwise kernels are HBM-bound; arithmetic follows the oracle's operation order (the library is
 // built with -ffp-contract=off), so K and b are bit-identical to it.
@@ -140,6 +144,8 @@ struct sri_rod_handle {
   uint32_t n = 0, m = 0;
   sri_apply_t* integ = nullptr;          // Dn_NN^-1 with the rank-1 initial-value epilogue
   double* d_nodes = nullptr;             // x_0 .. x_{n-1}, host libm cos (chebyshev_differentiation.h:26)
+  double* d_leg = nullptr;               // 2 x padded rows: P1, P2 of utilities.h:54-59 at the unknown nodes, zero padded
+  uint32_t leg_stride = 0;
   // workspace, grown on demand
   size_t cap_rods = 0;
   double *d_K = nullptr, *d_G = nullptr, *d_Qa = nullptr, *d_B = nullptr, *d_xb4 = nullptr, *d_xb3 = nullptr;
@@ -205,8 +211,20 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   h->integ = integ;
   std::vector<double> x(n);
   sri::cheb_points(n, 1.0, x.data());
+  // P1, P2 per unknown node, same operations as strain_kernel (this file is compiled with -ffp-contract=off)
+  h->leg_stride = sri::padded_rows(integ);
+  std::vector<double> leg(2 * static_cast<size_t>(h->leg_stride), 0.0);
+  for (uint32_t i = 0; i < h->m; ++i) {
+    const double xi = (2 * x[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+    const double P0 = 1.0, P1 = xi;
+    const double P2 = ((2 * 1 + 1) * xi * P1 - 1 * P0) / (1 + 1);
+    leg[i] = P1;
+    leg[h->leg_stride + i] = P2;
+  }
   if (hipMalloc(&h->d_nodes, sizeof(double) * n) != hipSuccess ||
       hipMemcpy(h->d_nodes, x.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&h->d_leg, sizeof(double) * leg.size()) != hipSuccess ||
+      hipMemcpy(h->d_leg, leg.data(), sizeof(double) * leg.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess) {
     sri_rod_destroy(h);
     return SRI_ENOMEM;
@@ -220,7 +238,7 @@ int sri_rod_destroy(sri_rod_t* h) {
   sri::RodDeviceGuard guard;
   (void)guard.enter(h->device);
   if (h->integ) sri_apply_destroy(h->integ);
-  double* bufs[] = {h->d_nodes, h->d_K, h->d_G, h->d_Qa, h->d_B, h->d_xb4, h->d_xb3, h->d_tips};
+  double* bufs[] = {h->d_nodes, h->d_leg, h->d_K, h->d_G, h->d_Qa, h->d_B, h->d_xb4, h->d_xb3, h->d_tips};
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (h->d_diff) (void)hipFree(h->d_diff);
@@ -252,6 +270,16 @@ int sri_rod_quaternion_rhs(sri_rod_t* h, const double* dK, size_t ldk, const dou
                      h->m, rods, dK, ldk, dQ, ldq, dG, ldg);
   ROD_HIP(hipGetLastError());
   return SRI_OK;
+}
+
+int sri_rod_quaternion_step(sri_rod_t* h, const double* d_qe, const double* dG, size_t ldg, const double* d_q_base, size_t rods,
+                            double* dG_next, size_t ldn, double* d_tips, void* stream) {
+  if (h == nullptr || (rods > 0 && (d_qe == nullptr || dG == nullptr || d_q_base == nullptr || dG_next == nullptr)) || ldg < h->m ||
+      ldn < h->m || dG == dG_next)
+    return SRI_EINVAL;
+  if (rods == 0) return SRI_OK;
+  const sri::QuatEpilogue epi{d_qe, h->d_leg, h->d_leg + h->leg_stride};
+  return sri::integrate_quat_step(h->integ, dG, ldg, d_q_base, epi, dG_next, ldn, 4 * rods, d_tips, stream);
 }
 
 int sri_rod_position_rhs(sri_rod_t* h, const double* dQ, size_t ldq, size_t rods, double* dB, size_t ldb, void* stream) {
@@ -286,21 +314,23 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
 
   rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, m, stream);
   if (rc != SRI_OK) return rc;
-  // Q^0 = q_init at every node; xb = the base value of every column
-  double* cur = dQ;            // ping-pong between the caller's panel and the workspace; result must end in dQ
-  double* nxt = h->d_Qa;
-  size_t ld_cur = ldq, ld_nxt = m;
+  // Q^0 = q_init at every node (in the caller's panel); xb = the base value of every column; G^0 = 1/2 A(K) Q^0
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
-                     qi[0], qi[1], qi[2], qi[3], cur, ld_cur, h->d_xb4);
+                     qi[0], qi[1], qi[2], qi[3], dQ, ldq, h->d_xb4);
   ROD_HIP(hipGetLastError());
+  double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = m)
+  double* nxt = h->d_Qa;
+  rc = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, cur, m, stream);
+  if (rc != SRI_OK) return rc;
 
-  // Fixed-point loop.  Convergence is monitored on the TIP node of every column — the Picard error of
-  // Q' = 1/2 A(K) Q grows with arc length, so the tip (node 0, X = 1) converges last — using the tip values the
-  // integration apply emits from its epilogue at no extra traffic (a full-panel max|dQ| would re-read 2 x 4
-  // columns per rod every iteration, ~25 % of the loop); the criterion is then CONFIRMED on the whole panel
-  // before returning, and the loop resumes with full checks should that ever fail.  The read-back is pipelined
-  // one iteration behind the launches so the device never idles on the host round trip; the price is at most
-  // one extra (harmless) iteration after convergence.
+  // Fixed-point loop, one fused launch per iteration:  G^{k+1} = 1/2 A(K) Q^{k+1},  Q^{k+1} = Dnn^-1 G^k - w q0^T.
+  // Convergence is monitored on the TIP node of every column of Q — the Picard error of Q' = 1/2 A(K) Q grows with
+  // arc length, so the tip (node 0, X = 1) converges last — using the tip values the apply emits from its epilogue
+  // at no extra traffic.  The read-back is pipelined one iteration behind the launches so the device never idles
+  // on the host round trip; the price is at most one extra (harmless) iteration after convergence.
+  // Once the tips have settled, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
+  // CONFIRMED on the whole panel:  max |1/2 A(K) Q - G|  bounds the next update of every entry of Q, because
+  // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with full-panel checks.
   uint32_t it = 0;
   double upd = INFINITY;
   unsigned long long* h_bits = nullptr;
@@ -314,17 +344,16 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
                      qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
   ROD_HIP(hipGetLastError());
+  const sri::QuatEpilogue epi{d_qe, h->d_leg, h->d_leg + h->leg_stride};
   auto enqueue = [&](uint32_t k) -> int {
-    int r = sri_rod_quaternion_rhs(h, h->d_K, m, cur, ld_cur, rods, h->d_G, m, stream);
-    if (r != SRI_OK) return r;
     double* tips_new = h->d_tips + (k & 1) * cols;
     double* tips_old = h->d_tips + ((k + 1) & 1) * cols;
-    r = sri_integrate_tips(h->integ, h->d_G, m, h->d_xb4, nxt, ld_nxt, cols, tips_new, stream);   // Q <- Dnn^-1 (G - Din q0^T)
+    int r = sri::integrate_quat_step(h->integ, cur, m, h->d_xb4, epi, nxt, m, cols, tips_new, stream);
     if (r != SRI_OK) return r;
     ROD_HIP(hipMemsetAsync(h->d_diff + (k & 1), 0, sizeof(unsigned long long), stream));
     if (full_checks)
-      hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, ld_nxt, cur, ld_cur,
-                         h->d_diff + (k & 1));
+      hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, static_cast<size_t>(m), cur,
+                         static_cast<size_t>(m), h->d_diff + (k & 1));
     else
       hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(256), dim3(256), 0, stream, 1u, cols, tips_new, static_cast<size_t>(1),
                          tips_old, static_cast<size_t>(1), h->d_diff + (k & 1));
@@ -332,7 +361,6 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     ROD_HIP(hipMemcpyAsync(h_bits + (k & 1), h->d_diff + (k & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipEventRecord(done[k & 1], stream));
     std::swap(cur, nxt);
-    std::swap(ld_cur, ld_nxt);
     return SRI_OK;
   };
   auto harvest = [&](uint32_t k) -> int {        // update size of iteration k
@@ -340,8 +368,24 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     std::memcpy(&upd, h_bits + (k & 1), sizeof(double));
     return SRI_OK;
   };
+  // Q from the newest right-hand side; then the bound on the next update over the whole panel -> upd
+  auto finish = [&]() -> int {
+    int r = sri_integrate(h->integ, cur, m, h->d_xb4, dQ, ldq, cols, stream);
+    if (r != SRI_OK) return r;
+    r = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, nxt, m, stream);
+    if (r != SRI_OK) return r;
+    ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, static_cast<size_t>(m), cur,
+                       static_cast<size_t>(m), h->d_diff);
+    ROD_HIP(hipGetLastError());
+    ROD_HIP(hipMemcpyAsync(h_bits, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    ROD_HIP(hipStreamSynchronize(stream));
+    std::memcpy(&upd, h_bits, sizeof(double));
+    return SRI_OK;
+  };
   rc = enqueue(0);
   it = 1;
+  bool finished = false;
   while (rc == SRI_OK) {
     const bool more = it < max_iter;
     if (more) {
@@ -353,27 +397,20 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     if (rc != SRI_OK) break;
     if (upd <= tol) {                                       // NaN compares false: runs to max_iter
       if (more) rc = harvest(it - 1);                       // the extra iteration in flight only tightens the result
-      if (rc != SRI_OK || full_checks) break;
-      // confirm on the whole panel: cur = newest iterate, nxt = the one before
-      ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
-      hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, cur, ld_cur, nxt, ld_nxt, h->d_diff);
-      ROD_HIP(hipGetLastError());
-      ROD_HIP(hipMemcpyAsync(h_bits, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-      ROD_HIP(hipStreamSynchronize(stream));
-      std::memcpy(&upd, h_bits, sizeof(double));
-      if (upd <= tol) break;
+      if (rc != SRI_OK) break;
+      rc = finish();
+      finished = true;
+      if (rc != SRI_OK || upd <= tol) break;
       full_checks = true;                                   // never observed; keep iterating with full-panel checks
+      finished = false;
       if (it >= max_iter) break;
       continue;
     }
     if (!more) break;
   }
+  if (rc == SRI_OK && !finished) rc = finish();             // iteration budget exhausted: still hand back the newest iterate
   cleanup();
   if (rc != SRI_OK) return rc;
-  if (cur != dQ) {                                           // result sits in the workspace: copy it out
-    ROD_HIP(hipMemcpy2DAsync(dQ, ldq * sizeof(double), cur, ld_cur * sizeof(double), m * sizeof(double), cols,
-                             hipMemcpyDeviceToDevice, stream));
-  }
   if (iters_out) *iters_out = it;
   if (last_update_out) *last_update_out = upd;
   return (upd <= tol) ? SRI_OK : SRI_ENOTCONVERGED;

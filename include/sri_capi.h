@@ -157,14 +157,24 @@ int sri_rod_strain_field(sri_rod_t *h, const double *d_qe, size_t rods, double *
 int sri_rod_quaternion_rhs(sri_rod_t *h, const double *dK, size_t ldk, const double *dQ, size_t ldq, size_t rods,
                            double *dG, size_t ldg, void *hip_stream);
 
+/* One Picard iteration of the quaternion system in ONE launch (main.cpp:69-84 + 103-113, batched):
+ *     Q      = Dn_NN^-1 G - (Dn_NN^-1 Dn_IN) q_base^T        (the integration apply with its initial-value term)
+ *     G_next = 1/2 A(K) Q,   K = Phi(X_i) qe                  (formed in the apply's store stage, no K / Q panel)
+ * dG, dG_next: m x (4*rods) panels (must not alias); d_q_base: 4*rods doubles, the base quaternion of every column;
+ * d_tips (optional, 4*rods): tip-node values of Q, for convergence monitoring. */
+int sri_rod_quaternion_step(sri_rod_t *h, const double *d_qe, const double *dG, size_t ldg, const double *d_q_base,
+                            size_t rods, double *dG_next, size_t ldn, double *d_tips, void *hip_stream);
+
 /* b_i = R(q_i) e1, updatePositionb (main.cpp:121-140). */
 int sri_rod_position_rhs(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods, double *dB, size_t ldb,
                          void *hip_stream);
 
 /* integrateQuaternions (main.cpp:91-118) for a batch: solves (I_4 (x) Dn_NN - 1/2 A(K)) Q = -D_IN q_init by the
- * fixed-point form Q <- Dn_NN^-1 (1/2 A(K) Q - Dn_IN q_init^T) on the MFMA integration apply, until the largest
- * update of any entry is <= tol (or max_iter: SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).
- * dQ: m x (4*rods).  Synchronises the stream once per iteration (convergence read-back). */
+ * fixed-point form Q <- Dn_NN^-1 (1/2 A(K) Q - Dn_IN q_init^T) on the MFMA integration apply (one fused launch per
+ * iteration, sri_rod_quaternion_step), until the largest update of any entry is <= tol (or max_iter:
+ * SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).  dQ: m x (4*rods).  *last_update: a bound on the
+ * next update of any entry of Q, max |1/2 A(K) Q - G| over the panel (||Dn_NN^-1||_inf = 1).  Synchronises the
+ * stream once per iteration (convergence read-back, pipelined one iteration behind the launches). */
 int sri_rod_integrate_quaternions(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, double *dQ,
                                   size_t ldq, double tol, uint32_t max_iter, uint32_t *iters, double *last_update,
                                   void *hip_stream);

@@ -73,6 +73,45 @@ def test_quaternion_rhs_kernel(sri):
     assert np.allclose(G, ref, rtol=0, atol=1e-15)
 
 
+@pytest.mark.parametrize("n,rods", [(16, 5), (17, 40), (10, 3), (33, 70), (64, 333), (65, 100), (129, 50), (200, 77),
+                                    (256, 700), (257, 96), (513, 33)])
+def test_fused_quaternion_step(sri, oracle, n, rods):
+    """sri_rod_quaternion_step (the right-hand side formed in the apply's store stage) against
+    (a) the unfused composition integrate -> strain -> rhs of the same library: bit-identical, same operation order;
+    (b) numpy on the oracle's Dn_NN^-1 / Dn_IN: 1e-12 relative Frobenius.  Covers all three geometries, the
+    register path (m < 16), tails (m % 16 != 0), whole multiples (m % 16 == 0) and ragged last column tiles."""
+    import torch
+
+    m = n - 1
+    rng = np.random.default_rng(n * 1000 + rods)
+    qe = rng.uniform(-2, 2, size=(rods, 9))
+    G = rng.uniform(-1, 1, size=(rods, 4, m))
+    q0 = rng.normal(size=(rods, 4))
+    rod = sri.RodIntegrator(n)
+    dqe, dG, dq0 = (torch.from_numpy(a).cuda() for a in (qe, G, q0))
+    tips = torch.full((rods, 4), float("nan"), dtype=torch.float64, device="cuda")
+    Gn = rod.quaternion_step(dqe, dG, dq0, tips=tips)
+    # (a) unfused, same library
+    integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+    Q = integ.integrate(dG.reshape(rods * 4, m), dq0.reshape(-1)).reshape(rods, 4, m)
+    ref = rod.quaternion_rhs(rod.strain_field(dqe), Q)
+    torch.cuda.synchronize()
+    assert torch.equal(Gn, ref)
+    assert torch.equal(tips, Q[:, :, 0])
+    # (b) oracle matrices
+    Dinv, Din = oracle.integration(n)
+    w = Dinv @ Din
+    Qo = np.einsum("ik,rck->rci", Dinv, G) - w[None, None, :] * q0[:, :, None]
+    x = oracle.points(n)
+    Ko = np.stack([np.stack([oracle.strain(x[i], q) for i in range(m)], axis=1) for q in qe])
+    k0, k1, k2 = Ko[:, 0], Ko[:, 1], Ko[:, 2]
+    qw, qx, qy, qz = Qo[:, 0], Qo[:, 1], Qo[:, 2], Qo[:, 3]
+    Go = 0.5 * np.stack([-k0 * qx - k1 * qy - k2 * qz, k0 * qw + k2 * qy - k1 * qz, k1 * qw - k2 * qx + k0 * qz,
+                         k2 * qw + k1 * qx - k0 * qy], axis=1)
+    rel = np.linalg.norm(Gn.cpu().numpy() - Go) / np.linalg.norm(Go)
+    assert rel <= 1e-12, rel
+
+
 def test_large_batch_properties(sri):
     """N=256, 4096 rods: too many for the dense oracle — check invariants of the exact solution instead."""
     import torch
