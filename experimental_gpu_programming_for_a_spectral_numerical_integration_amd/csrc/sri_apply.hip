@@ -48,6 +48,7 @@
 #include <type_traits>
 #include <vector>
 
+#define SRI_DEVICE_HELPERS 1
 #include "sri_internal.h"
 
 namespace sri {
@@ -96,6 +97,16 @@ struct Geo {
   static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
   static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
   static constexpr int NSTORE = TM * TN * 2;                            // 16-byte Y stores per lane of a full tile
+  // EPI_QUAT: the strain coefficients of a tile's rods (BN/4 rods x 9 doubles, contiguous in memory) travel with the
+  // tile's first stage into a side buffer behind the ring; QE_BUFS tiles may be between "issued" and "epilogue read".
+  // Each buffer also holds the Legendre factor P1 of the tile's BM rows.  Two buffers are enough when a tile has
+  // >= 3 k chunks, one-chunk tiles need four (see issue_qe); the count is a launch parameter.
+  static constexpr int QE_BYTES = (BN / 4 * 72 + 255) / 256 * 256;      // whole 256-byte wave pieces
+  static constexpr int P1_BYTES = BM * 8;
+  static constexpr int SIDE_BYTES = QE_BYTES + P1_BYTES;
+  static constexpr int lds_bytes_quat(int bufs) { return LDS_BYTES + bufs * SIDE_BYTES; }
+  static_assert(LDS_BYTES + 2 * SIDE_BYTES <= 160 * 1024, "ring + side buffers exceed a CU");
+  static_assert(P1_BYTES <= NW * 1024 && P1_BYTES % 512 == 0, "P1 slab: at most one (half or whole) 1-KiB DMA piece per wave");
   static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
@@ -109,9 +120,9 @@ struct ApplyArgs {
   const double* w;       // optional rank-1 epilogue: y -= w[row] * xb[col]   (w padded to row_blocks*BM)
   const double* xb;
   double* tips;          // optional: tips[col] = Y[0][col], the rod-tip node (chebyshev_differentiation.h:26: x_0 = L)
-  const double* qe;      // EPI_QUAT only: strain coefficients, 9 per rod (main.cpp:17, 187-195)
-  const double* leg1;    // EPI_QUAT only: P1, P2 of utilities.h:54-59 at the node of every (padded) row
-  const double* leg2;
+  const double* qe;      // EPI_QUAT only: strain coefficients, 9 per rod (main.cpp:17, 187-195); m/4 rods
+  const double* leg1;    // EPI_QUAT only: P1 of utilities.h:54-59 (= 2X - 1) at the node of every (padded) row
+  uint32_t side_bufs;    // EPI_QUAT only: side buffers behind the ring (2 or 4)
   size_t ldx, ldy, m;    // m = number of columns
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
@@ -176,6 +187,11 @@ enum { EPI_NONE = 0, EPI_QUAT = 1 };
 template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
+  // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
+  // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
+  // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
+  constexpr bool FOLD = RANK1 && (TAIL || !DMA);
+  constexpr bool RANK1_EPI = RANK1 && !FOLD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
@@ -209,6 +225,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   int xsafe[(DMA && TAIL) ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
   const char* asrc;
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
+  uint32_t tseq_i = 0;       // EPI_QUAT: how many tiles the issue cursor has left behind (selects the qe side buffer)
+  uint32_t tseq_c = 0;       // ... and how many tiles this wave has finished (side buffer of the one in the accumulators)
   size_t col0_i = 0;
   auto issue_setup = [&]() __attribute__((always_inline)) {
     const uint32_t rb = tile_i / p.col_tiles;
@@ -236,8 +254,45 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   double xreg[DMA ? 1 : XR];
 
   bool abl_first = true;   // ablation builds only
+  // EPI_QUAT, first stage of a tile: the 72 bytes of strain coefficients of each of the tile's BN/4 rods and the
+  // Legendre factor P1 of its BM rows, by LDS-DMA into side buffer (tile sequence % side_bufs).  Issued BEFORE the
+  // stage's own pieces: vmcnt retires in order, so the wait for stage (tile, 0) — which every wave passes, followed
+  // by a barrier, before the tile's epilogue — covers them.  Reuse: the pieces of tile j are issued in the body of
+  // stage (j, 0) - 2, after that stage's barrier; the late wave group reads the buffer of tile i in the body of stage
+  // (i+1, 0), before barrier (i+1, 1).  With nk >= 3 chunks per tile, (j, 0) - 2 >= (j-1, 1): two buffers suffice;
+  // with nk = 2 three, with nk = 1 (issue of tile j and epilogue of tile j-3 share a body) four.
+  auto issue_qe = [&]() __attribute__((always_inline)) {
+    if constexpr (EPI == EPI_QUAT) {
+      if (kc_i == 0) {
+        // 4-byte pieces (256 B per wave instruction): the caller's array ends exactly after the last rod, and a
+        // 4-byte granule can be clamped at that end without shifting valid data.
+        const size_t total = (p.m >> 2) * 72;                          // >= 72: at least one rod
+        const size_t base = (col0_i >> 2) * 72;
+        char* buf = smem + G::LDS_BYTES + (tseq_i % p.side_bufs) * G::SIDE_BYTES;
+#pragma unroll
+        for (int i = 0; i < (G::QE_BYTES / 256 + NW - 1) / NW; ++i) {
+          const int chunk = wid + i * NW;                              // wave-uniform
+          if (chunk * 256 < G::QE_BYTES) {
+            size_t src = base + chunk * 256 + lane * 4;
+            src = src + 4 <= total ? src : total - 4;                  // ragged last tile: re-read valid bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.qe) + src),
+                                             (__attribute__((address_space(3))) void*)(buf + chunk * 256), 4, 0, 0);
+          }
+        }
+        // P1 of the tile's row block: the table is padded to whole row blocks and 16-byte aligned; the last waves
+        // take it (the first ones carry the extra coefficient piece)
+        const int pw = NW - 1 - wid;                                   // wave-uniform
+        if (pw * 1024 < G::P1_BYTES && pw * 1024 + lane * 16 < G::P1_BYTES) {
+          const uint32_t rb = tile_i / p.col_tiles;
+          lds_dma16(reinterpret_cast<const char*>(p.leg1 + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
+                    buf + G::QE_BYTES + pw * 1024);
+        }
+      }
+    }
+  };
   // Fetch the stage under the cursor into ring slot slot_i; advance the cursor.
   auto stage_issue = [&]() __attribute__((always_inline)) {
+    issue_qe();
     char* sA = smem + slot_i * G::STAGE_BYTES;
     const char* gA = asrc + static_cast<size_t>(kc_i) * G::A_BYTES;
     if (!(ABL & 1) || abl_first) {
@@ -267,6 +322,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         const size_t col = col0_i + cc;
         const uint32_t kk = kc_i * BK + k;
         xreg[r] = (col < p.m && kk < p.rows) ? p.x[col * p.ldx + kk] : 0.0;
+        if constexpr (FOLD) { if (col < p.m && kk == p.rows) xreg[r] = p.xb[col]; }
       }
     }
   };
@@ -274,6 +330,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // the operator slab, the rest the X panel.  Lets the main loop drop the pieces between MFMA groups.
   auto issue_piece = [&](int idx) __attribute__((always_inline)) {
     char* sA = smem + slot_i * G::STAGE_BYTES;
+    if (idx == 0) issue_qe();
     if (idx < G::A_DMA_PER_WAVE) {
       if (!(ABL & 1) || abl_first) {
         const int i = wid + idx * NW;
@@ -308,6 +365,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
     if (++kc_i == p.nk) {
       kc_i = 0;
+      ++tseq_i;
       tile_i += gridDim.x;
       if (issued < total_stages) issue_setup();
     }
@@ -391,7 +449,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         const size_t col = col_base + tn * 16 + r * 4;
         if (col < p.m) {
           double v = acc[0][tn][r];
-          if constexpr (RANK1) v -= p.w[0] * p.xb[col];
+          if constexpr (RANK1_EPI) v -= p.w[0] * p.xb[col];
           p.tips[col] = v;
         }
       }
@@ -408,41 +466,48 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
     const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
     const bool tip_lane = p.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
+    const char* side = smem + G::LDS_BYTES + (tseq_c % p.side_bufs) * G::SIDE_BYTES;
+    d2 p1[TM / 2];                                               // P1 at this lane's row pairs
+#pragma unroll
+    for (int t = 0; t < TM / 2; ++t)
+      p1[t] = *reinterpret_cast<const d2*>(side + G::QE_BYTES + (wm * (TM * 16) + 2 * c + 32 * t) * 8);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const size_t col = col_base4 + tn * 16;
       if (!full && col >= p.m) continue;                       // m is a multiple of 4: a rod is in or out as a whole
-      const double* qe = p.qe + (col >> 2) * 9;
-      double q9[9], xb[4];
+      const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
+      double q9[9], xb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < 9; ++i) q9[i] = qe[i];
+      if constexpr (RANK1_EPI) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[r] = p.xb[col + r];
+        for (int r = 0; r < 4; ++r) xb[r] = p.xb[col + r];
+      }
 #pragma unroll
       for (int t = 0; t < TM / 2; ++t) {
         const uint32_t row = row_base + 32 * t;
         double gq[2][4];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const double wv = p.w[row + e], P1 = p.leg1[row + e], P2 = p.leg2[row + e];   // tables are zero padded
-          const double qw = acc[2 * t + e][tn][0] - wv * xb[0], qx = acc[2 * t + e][tn][1] - wv * xb[1];
-          const double qy = acc[2 * t + e][tn][2] - wv * xb[2], qz = acc[2 * t + e][tn][3] - wv * xb[3];
+          const double P1 = p1[t][e];
+          const double P2 = ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1);   // as strain_kernel (sri_rod.hip)
+          double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
+          if constexpr (RANK1_EPI) {
+            const double wv = p.w[row + e];
+            qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
+          }
           if (tip_lane && t == 0 && e == 0) {
             p.tips[col + 0] = qw; p.tips[col + 1] = qx; p.tips[col + 2] = qy; p.tips[col + 3] = qz;
           }
-          double k[3];
+          double hk[3];                                          // K/2: halving is exact
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            double s = 0.0;
-            s = s + 1.0 * q9[a * 3 + 0];
+            double s = q9[a * 3 + 0];                             // P0 = 1
             s = s + P1 * q9[a * 3 + 1];
             s = s + P2 * q9[a * 3 + 2];
-            k[a] = s;
+            hk[a] = 0.5 * s;
           }
-          gq[e][0] = 0.5 * (((0.0 - k[0] * qx) - k[1] * qy) - k[2] * qz);
-          gq[e][1] = 0.5 * ((k[0] * qw + k[2] * qy) - k[1] * qz);
-          gq[e][2] = 0.5 * ((k[1] * qw - k[2] * qx) + k[0] * qz);
-          gq[e][3] = 0.5 * ((k[2] * qw + k[1] * qx) - k[0] * qy);
+          quat_rhs_half(hk[0], hk[1], hk[2], qw, qx, qy, qz, gq[e]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -479,7 +544,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     } else if (full) {
       // rank-1 term: this lane's TM row factors once per tile, one x_base value per column (not per store)
       double wv[TM / 2][2];
-      if constexpr (RANK1) {
+      if constexpr (RANK1_EPI) {
 #pragma unroll
         for (int t = 0; t < TM / 2; ++t) {
           wv[t][0] = p.w[row_base + 32 * t];
@@ -492,13 +557,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int r = 0; r < 4; ++r) {
           const size_t col = col_base + tn * 16 + r * 4;
           double xbv = 0.0;
-          if constexpr (RANK1) xbv = p.xb[col];
+          if constexpr (RANK1_EPI) xbv = p.xb[col];
 #pragma unroll
           for (int t = 0; t < TM / 2; ++t) {
             const uint32_t row = row_base + 32 * t;
             double* yp = p.y + col * p.ldy + row;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
-            if constexpr (RANK1) {
+            if constexpr (RANK1_EPI) {
               v0 -= wv[t][0] * xbv;
               v1 -= wv[t][1] * xbv;
             }
@@ -517,12 +582,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           if (col >= p.m) continue;
           double* ycol = p.y + col * p.ldy;
           double xbv = 0.0;
-          if constexpr (RANK1) xbv = p.xb[col];
+          if constexpr (RANK1_EPI) xbv = p.xb[col];
 #pragma unroll
           for (int t = 0; t < TM / 2; ++t) {
             const uint32_t row = row_base + 32 * t;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
-            if constexpr (RANK1) {
+            if constexpr (RANK1_EPI) {
               if (row < p.rows) v0 -= p.w[row] * xbv;
               if (row + 1 < p.rows) v1 -= p.w[row + 1] * xbv;
             }
@@ -592,6 +657,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       const size_t col = col0_s + cc;
       double v = 0.0;
       if (col < p.m && kbase + kk < p.rows) v = p.x[col * p.ldx + kbase + kk];
+      if constexpr (FOLD) { if (col < p.m && kbase + kk == p.rows) v = p.xb[col]; }
       const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & 7);
       *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
     }
@@ -626,6 +692,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       if constexpr ((ABL & 4) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // edge tile: unknown store count, drain
       since_store = 99;
     }
+    ++tseq_c;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -813,8 +880,10 @@ struct sri_apply_handle {
 
 namespace sri {
 
+// `w` (optional, rows % 16 != 0 only): the rank-1 factor, packed negated as operator column k = rows — the free slot of
+// the last k chunk; the kernel puts x_base[col] (or 0 for a plain apply) into the matching slot of the X image.
 template <class G>
-static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t nk, uint32_t row_blocks,
+static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t nk, uint32_t row_blocks, const double* w,
                           std::vector<double>& out) {
   out.assign(static_cast<size_t>(row_blocks) * nk * G::BM * BK, 0.0);
   size_t o = 0;
@@ -827,27 +896,32 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
               const uint32_t row = rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15);
               const uint32_t k = kc * BK + k_of(j, l >> 4, e);
               if (row < rows && k < rows) out[o] = A[row + static_cast<size_t>(k) * lda];
+              else if (w != nullptr && row < rows && k == rows) out[o] = -w[row];
             }
 }
 
 // Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
 // that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
 // inside a stream capture (HIP graph).
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
 static int& residency(int dev) {
   static int blocks_per_cu[16] = {};
   return blocks_per_cu[dev];
 }
 
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
 static int prepare(int dev) {
   if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1, TAIL, EPI>(dev) != 0) return SRI_OK;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev) != 0) return SRI_OK;
   const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>;
-  SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+  constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
+  static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
+  // the attribute is the most any launch of this kernel may ask for
+  constexpr int lds_max = EPI != EPI_QUAT ? lds : (G::lds_bytes_quat(4) <= 160 * 1024 ? G::lds_bytes_quat(4) : G::lds_bytes_quat(2));
+  SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
   int nb = 0;
-  SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
-  residency<G, DMA, RANK1, TAIL, EPI>(dev) = nb < 1 ? 1 : nb;
+  SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
+  residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev) = nb < 1 ? 1 : nb;
   return SRI_OK;
 }
 
@@ -859,26 +933,32 @@ static int prepare_geometry(int dev) {
   if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT>(dev);
-  if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
+  if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
+  if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
+    if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 4>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 4>(dev);
+    if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT, 4>(dev);
+  }
   return rc;
 }
 
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream) {
-  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI>(dev);
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;
   if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
   args.col_tiles = static_cast<uint32_t>(col_tiles);
+  args.side_bufs = BUFS;
   size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, args);
+  constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
+  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>), dim3(grid), dim3(G::THREADS), lds, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -890,9 +970,17 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0;
   if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
-    if (dma && tail) return launch<G, true, true, true, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
-    if (dma) return launch<G, true, true, false, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
-    return launch<G, false, true, false, EPI_QUAT>(args, col_tiles, dev, cus, cap, stream);
+    if (args.nk >= 3) {
+      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream);
+      if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream);
+      return SRI_EUNSUPPORTED;                             // register-staged build: rows < 16, one chunk
+    }
+    if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {
+      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
+      if (dma) return launch<G, true, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
+      return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
+    }
+    return SRI_EUNSUPPORTED;
   }
   if (dma && tail) return rank1 ? launch<G, true, true, true>(args, col_tiles, dev, cus, cap, stream)
                                 : launch<G, true, false, true>(args, col_tiles, dev, cus, cap, stream);
@@ -975,9 +1063,10 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
 
   std::vector<double> packed;
   try {
-    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, packed);
-    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, packed);
-    else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, packed);
+    const double* wf = (rows % BK != 0) ? w_host : nullptr;
+    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
+    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
+    else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
   } catch (const std::bad_alloc&) {
     delete h;
     return SRI_ENOMEM;
@@ -1008,7 +1097,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   if (M == 0) return SRI_OK;
   const bool rank1 = d_xb != nullptr;
   if (rank1 && h->d_w == nullptr) return SRI_EINVAL;
-  if (quat != nullptr && (!rank1 || M % 4 != 0 || quat->qe == nullptr || quat->leg1 == nullptr || quat->leg2 == nullptr))
+  if (quat != nullptr && (!rank1 || M % 4 != 0 || quat->qe == nullptr || quat->leg1 == nullptr))
     return SRI_EINVAL;
   DeviceGuard guard;
   int rc = guard.enter(h->device);
@@ -1023,7 +1112,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.tips = d_tips;
   args.qe = quat ? quat->qe : nullptr;
   args.leg1 = quat ? quat->leg1 : nullptr;
-  args.leg2 = quat ? quat->leg2 : nullptr;
+  args.side_bufs = 0;   // set by launch()
   args.ldx = ldx;
   args.ldy = ldy;
   args.m = M;

@@ -24,11 +24,10 @@ void record_hip_error(int hip_error);
 // ---- fused Picard iteration of the quaternion system (sri_apply.hip, used by sri_rod.hip) ----------
 // G_next = 1/2 A(K) (Dn_NN^-1 G - (Dn_NN^-1 Dn_IN) x_base^T),  K = Phi(X_row) qe, in ONE launch of the integration
 // apply: the right-hand side of main.cpp:71-84 is formed in the store stage from the accumulators.  All pointers are
-// device pointers; leg1/leg2 hold P1/P2 of utilities.h:54-59 per row, zero padded to padded_rows(h).
+// device pointers; leg1 holds P1 of utilities.h:54-59 (= 2X - 1) per row, zero padded to padded_rows(h).
 struct QuatEpilogue {
   const double* qe;     // 9 per rod
   const double* leg1;
-  const double* leg2;
 };
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream);
@@ -49,6 +48,21 @@ constexpr int kChunkK = 16;   // k extent of one pipeline stage (BK)
 inline constexpr int row_of_slot(int tm, int j) { return 32 * (tm >> 1) + 2 * j + (tm & 1); }
 // k index inside a chunk for lane k-slot g, k-pair j, element e of the 16-byte fragment read:
 inline constexpr int k_of(int j, int g, int e) { return 8 * j + 2 * g + e; }
+
+#if defined(SRI_DEVICE_HELPERS)   /* defined by the .hip translation units after <hip/hip_runtime.h> */
+// G = 1/2 A(K) q of main.cpp:71-84 with hk = K/2:  A(K) = [0 -k0 -k1 -k2; k0 0 k2 -k1; k1 -k2 0 k0; k2 k1 -k0 0].
+// One product and two fused multiply-adds per component — f64 VALU work shares the MFMA pipe.  The stand-alone
+// kernel of sri_rod.hip and the fused epilogue of sri_apply.hip use the same
+// function, so fused and unfused iterations agree bit for bit.
+__device__ __forceinline__ void quat_rhs_half(double h0, double h1, double h2, double w, double x, double y, double z,
+                                              double (&g)[4]) {
+  g[0] = __builtin_fma(-h2, z, __builtin_fma(-h1, y, -(h0 * x)));
+  g[1] = __builtin_fma(-h1, z, __builtin_fma(h2, y, h0 * w));
+  g[2] = __builtin_fma(h0, z, __builtin_fma(-h2, x, h1 * w));
+  g[3] = __builtin_fma(-h0, y, __builtin_fma(h1, x, h2 * w));
+}
+
+#endif
 
 }  // namespace sri
 

@@ -29,6 +29,7 @@
 #include <new>
 #include <vector>
 
+#define SRI_DEVICE_HELPERS 1
 #include "sri_internal.h"
 
 namespace sri {
@@ -59,8 +60,7 @@ __global__ void strain_kernel(uint32_t m, size_t rods, const double* __restrict_
   const double* q = qe + rod * 9;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    double s = 0.0;
-    s = s + P0 * q[a * 3 + 0];
+    double s = P0 * q[a * 3 + 0];
     s = s + P1 * q[a * 3 + 1];
     s = s + P2 * q[a * 3 + 2];
     K[(rod * 3 + a) * ld + i] = s;
@@ -77,10 +77,11 @@ __global__ void quat_rhs_kernel(uint32_t m, size_t rods, const double* __restric
   const double w = Q[(rod * 4 + 0) * ldq + i], x = Q[(rod * 4 + 1) * ldq + i];
   const double y = Q[(rod * 4 + 2) * ldq + i], z = Q[(rod * 4 + 3) * ldq + i];
   // main.cpp:72-75:  A(K) = [0 -k0 -k1 -k2; k0 0 k2 -k1; k1 -k2 0 k0; k2 k1 -k0 0],  G = 0.5 * A(K) * q
-  G[(rod * 4 + 0) * ldg + i] = 0.5 * (((0.0 - k0 * x) - k1 * y) - k2 * z);
-  G[(rod * 4 + 1) * ldg + i] = 0.5 * ((k0 * w + k2 * y) - k1 * z);
-  G[(rod * 4 + 2) * ldg + i] = 0.5 * ((k1 * w - k2 * x) + k0 * z);
-  G[(rod * 4 + 3) * ldg + i] = 0.5 * ((k2 * w + k1 * x) - k0 * y);
+  // (halving K is exact; same function as the fused epilogue of the apply, so both agree bit for bit)
+  double gq[4];
+  quat_rhs_half(0.5 * k0, 0.5 * k1, 0.5 * k2, w, x, y, z, gq);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) G[(rod * 4 + a) * ldg + i] = gq[a];
 }
 
 __global__ void position_rhs_kernel(uint32_t m, size_t rods, const double* __restrict__ Q, size_t ldq,
@@ -144,8 +145,7 @@ struct sri_rod_handle {
   uint32_t n = 0, m = 0;
   sri_apply_t* integ = nullptr;          // Dn_NN^-1 with the rank-1 initial-value epilogue
   double* d_nodes = nullptr;             // x_0 .. x_{n-1}, host libm cos (chebyshev_differentiation.h:26)
-  double* d_leg = nullptr;               // 2 x padded rows: P1, P2 of utilities.h:54-59 at the unknown nodes, zero padded
-  uint32_t leg_stride = 0;
+  double* d_leg = nullptr;               // P1 of utilities.h:54-59 (= 2X - 1) at the unknown nodes, zero padded to the row blocks
   // workspace, grown on demand
   size_t cap_rods = 0;
   double *d_K = nullptr, *d_G = nullptr, *d_Qa = nullptr, *d_B = nullptr, *d_xb4 = nullptr, *d_xb3 = nullptr;
@@ -211,16 +211,9 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   h->integ = integ;
   std::vector<double> x(n);
   sri::cheb_points(n, 1.0, x.data());
-  // P1, P2 per unknown node, same operations as strain_kernel (this file is compiled with -ffp-contract=off)
-  h->leg_stride = sri::padded_rows(integ);
-  std::vector<double> leg(2 * static_cast<size_t>(h->leg_stride), 0.0);
-  for (uint32_t i = 0; i < h->m; ++i) {
-    const double xi = (2 * x[i] - (1.0 + 0.0)) / (1.0 - 0.0);
-    const double P0 = 1.0, P1 = xi;
-    const double P2 = ((2 * 1 + 1) * xi * P1 - 1 * P0) / (1 + 1);
-    leg[i] = P1;
-    leg[h->leg_stride + i] = P2;
-  }
+  // P1 per unknown node, same operations as strain_kernel (this file is compiled with -ffp-contract=off)
+  std::vector<double> leg(sri::padded_rows(integ), 0.0);
+  for (uint32_t i = 0; i < h->m; ++i) leg[i] = (2 * x[i] - (1.0 + 0.0)) / (1.0 - 0.0);
   if (hipMalloc(&h->d_nodes, sizeof(double) * n) != hipSuccess ||
       hipMemcpy(h->d_nodes, x.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_leg, sizeof(double) * leg.size()) != hipSuccess ||
@@ -278,7 +271,7 @@ int sri_rod_quaternion_step(sri_rod_t* h, const double* d_qe, const double* dG, 
       ldn < h->m || dG == dG_next)
     return SRI_EINVAL;
   if (rods == 0) return SRI_OK;
-  const sri::QuatEpilogue epi{d_qe, h->d_leg, h->d_leg + h->leg_stride};
+  const sri::QuatEpilogue epi{d_qe, h->d_leg};
   return sri::integrate_quat_step(h->integ, dG, ldg, d_q_base, epi, dG_next, ldn, 4 * rods, d_tips, stream);
 }
 
@@ -344,7 +337,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
                      qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
   ROD_HIP(hipGetLastError());
-  const sri::QuatEpilogue epi{d_qe, h->d_leg, h->d_leg + h->leg_stride};
+  const sri::QuatEpilogue epi{d_qe, h->d_leg};
   auto enqueue = [&](uint32_t k) -> int {
     double* tips_new = h->d_tips + (k & 1) * cols;
     double* tips_old = h->d_tips + ((k + 1) & 1) * cols;

@@ -5,7 +5,8 @@ Prints one JSON line: rods/s for quaternion + position integration of `--rods` r
 fixed-point iteration count, and a per-kernel breakdown.  The elementwise kernels are HBM-bound and are
 priced against the 8 TB/s HBM roofline with their algorithmic bytes (per rod and node: strain 3 doubles
 written; quaternion RHS 7 read + 4 written; position RHS 4 read + 3 written); the integration apply is
-the MFMA kernel of bench.py (8 (N-1)^2 flop per 4 columns)."""
+the MFMA kernel of bench.py (8 (N-1)^2 flop per 4 columns), and the fused Picard step is that kernel with
+the quaternion right-hand side formed in its store stage (4 columns in, 4 out per rod)."""
 import argparse
 import json
 import os
@@ -64,6 +65,7 @@ def main():
     xb = torch.zeros((rods, 4), dtype=torch.float64, device=dev)
     out = torch.empty_like(G)
     ms_apply4 = timed(lambda: integ.integrate(G, xb, out=out))
+    ms_step = timed(lambda: rod.quaternion_step(qe, G, xb))       # the fused Picard iteration (one launch)
     el = lambda cols_moved, ms: cols_moved * m * 8.0 * rods / (ms * 1e-3) / 1e9
     res = {
         "metric": "rods/s (quaternion + position integration, fp64)", "value": rods / best, "unit": "rods/s",
@@ -71,12 +73,14 @@ def main():
         "last_update": rod.last_update,
         "unit_quaternion_defect_max": float((Q.pow(2).sum(dim=1).sqrt() - 1).abs().max()),
         "breakdown_ms": {"strain_field": ms_strain, "quaternion_rhs": ms_qrhs, "position_rhs": ms_prhs,
-                         "integration_apply_4cols": ms_apply4},
+                         "integration_apply_4cols": ms_apply4, "fused_picard_step": ms_step},
         "hbm_GBps": {"strain_field": el(3, ms_strain), "quaternion_rhs": el(11, ms_qrhs), "position_rhs": el(7, ms_prhs)},
         "hbm_frac_of_8TBps": {"strain_field": el(3, ms_strain) / 8000, "quaternion_rhs": el(11, ms_qrhs) / 8000,
                               "position_rhs": el(7, ms_prhs) / 8000},
         "integration_apply_TFLOPs": 8.0 * m * m * rods / (ms_apply4 * 1e-3) / 1e12,
-        "model_ms": iters * (ms_qrhs + ms_apply4) + ms_strain + ms_prhs + ms_apply4 * 0.75,
+        "fused_step_TFLOPs": 8.0 * m * m * rods / (ms_step * 1e-3) / 1e12,
+        "fused_step_hbm_GBps": el(8, ms_step),
+        "model_ms": iters * ms_step + ms_strain + 2 * ms_qrhs + ms_prhs + ms_apply4 * 1.75,
     }
     # CPU baseline: the oracle's restatement of main.cpp (dense per-rod solve), single thread, bounded sample
     try:
