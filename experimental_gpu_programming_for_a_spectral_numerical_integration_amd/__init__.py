@@ -56,7 +56,7 @@ C_ABI = {
     "sri_rod_destroy": (_int, [_vp]),
     "sri_rod_strain_field": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
-    "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
     "sri_rod_integrate_positions": (_int, [_vp, _vp, _sz, _sz, _dp, _vp, _sz, _vp]),
@@ -342,12 +342,16 @@ class RodIntegrator:
                                                    G.data_ptr(), self.m, self._stream(Q)), "sri_rod_quaternion_rhs")
         return G
 
-    def quaternion_step(self, qe, G, q_base, tips=None):
-        """One fused Picard iteration (sri_rod_quaternion_step): returns G_next = 1/2 A(K) (Dnn^-1 G - w q_base^T)."""
+    def quaternion_step(self, qe, G, q_base, tips=None, tips_prev=None, update=None):
+        """One fused Picard iteration (sri_rod_quaternion_step): returns G_next = 1/2 A(K) (Dnn^-1 G - w q_base^T).
+
+        ``tips`` receives the tip-node values of Q; with ``tips_prev`` and ``update`` (a zeroed int64 CUDA scalar)
+        the launch also accumulates the bits of ``max |tips - tips_prev|`` into ``update``."""
         import torch
         Gn = torch.empty_like(G)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         _chk(load_library().sri_rod_quaternion_step(self._h, qe.data_ptr(), G.data_ptr(), self.m, q_base.data_ptr(), G.shape[0],
-                                                    Gn.data_ptr(), self.m, tips.data_ptr() if tips is not None else None,
+                                                    Gn.data_ptr(), self.m, ptr(tips), ptr(tips_prev), ptr(update),
                                                     self._stream(G)), "sri_rod_quaternion_step")
         return Gn
 

@@ -103,10 +103,12 @@ struct Geo {
   // >= 3 k chunks, one-chunk tiles need four (see issue_qe); the count is a launch parameter.
   static constexpr int QE_BYTES = (BN / 4 * 72 + 255) / 256 * 256;      // whole 256-byte wave pieces
   static constexpr int P1_BYTES = BM * 8;
-  static constexpr int SIDE_BYTES = QE_BYTES + P1_BYTES;
+  static constexpr int TIPS_BYTES = BN * 8;                             // previous tip value of every column (convergence monitor)
+  static constexpr int SIDE_BYTES = QE_BYTES + P1_BYTES + TIPS_BYTES;
   static constexpr int lds_bytes_quat(int bufs) { return LDS_BYTES + bufs * SIDE_BYTES; }
   static_assert(LDS_BYTES + 2 * SIDE_BYTES <= 160 * 1024, "ring + side buffers exceed a CU");
-  static_assert(P1_BYTES <= NW * 1024 && P1_BYTES % 512 == 0, "P1 slab: at most one (half or whole) 1-KiB DMA piece per wave");
+  static_assert(P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 && (P1_BYTES + 1023) / 1024 + 1 <= NW,
+                "P1 slab and previous tips: at most one (half or whole) 1-KiB DMA piece per wave");
   static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
@@ -123,6 +125,9 @@ struct ApplyArgs {
   const double* qe;      // EPI_QUAT only: strain coefficients, 9 per rod (main.cpp:17, 187-195); m/4 rods
   const double* leg1;    // EPI_QUAT only: P1 of utilities.h:54-59 (= 2X - 1) at the node of every (padded) row
   uint32_t side_bufs;    // EPI_QUAT only: side buffers behind the ring (2 or 4)
+  const double* tips_prev;   // EPI_QUAT, optional: tip values of the previous iterate, and
+  double* partial;           //   partial[block * WN + wn] = this wave column's largest |tip - previous tip| (NaN if any)
+  const unsigned long long* stop;   // optional: the launch does nothing if *stop != 0 (device-driven fixed-point loops)
   size_t ldx, ldy, m;    // m = number of columns
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
@@ -206,6 +211,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   const int tid = threadIdx.x;
+  if constexpr (EPI == EPI_QUAT) {
+    if (p.stop != nullptr && *p.stop != 0ull) return;          // uniform over the grid: the loop has already converged
+  }
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
   uint32_t tseq_i = 0;       // EPI_QUAT: how many tiles the issue cursor has left behind (selects the qe side buffer)
   uint32_t tseq_c = 0;       // ... and how many tiles this wave has finished (side buffer of the one in the accumulators)
+  double tip_update = 0.0;   // EPI_QUAT monitor: largest |tip - previous tip| this lane has seen over all its tiles
   size_t col0_i = 0;
   auto issue_setup = [&]() __attribute__((always_inline)) {
     const uint32_t rb = tile_i / p.col_tiles;
@@ -286,6 +295,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           const uint32_t rb = tile_i / p.col_tiles;
           lds_dma16(reinterpret_cast<const char*>(p.leg1 + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
                     buf + G::QE_BYTES + pw * 1024);
+        }
+        // previous tip values of the tile's columns (m is a multiple of 4, so 16-byte granules never straddle the end)
+        if (p.tips_prev != nullptr && pw == (G::P1_BYTES + 1023) / 1024 && lane * 16 < G::TIPS_BYTES) {
+          size_t src = col0_i * 8 + lane * 16;
+          src = src + 16 <= p.m * 8 ? src : p.m * 8 - 16;
+          lds_dma16(reinterpret_cast<const char*>(p.tips_prev) + src, buf + G::QE_BYTES + G::P1_BYTES);
         }
       }
     }
@@ -467,6 +482,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
     const bool tip_lane = p.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
     const char* side = smem + G::LDS_BYTES + (tseq_c % p.side_bufs) * G::SIDE_BYTES;
+    const bool monitor = p.partial != nullptr && rb_c == 0 && wm == 0;         // wave-uniform
     d2 p1[TM / 2];                                               // P1 at this lane's row pairs
 #pragma unroll
     for (int t = 0; t < TM / 2; ++t)
@@ -498,6 +514,15 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           }
           if (tip_lane && t == 0 && e == 0) {
             p.tips[col + 0] = qw; p.tips[col + 1] = qx; p.tips[col + 2] = qy; p.tips[col + 3] = qz;
+            if (monitor) {
+              const double* old = reinterpret_cast<const double*>(side + G::QE_BYTES + G::P1_BYTES) + (wn * TN + tn) * 16 + 4 * g;
+              const double qv[4] = {qw, qx, qy, qz};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const double d = fabs(qv[r] - old[r]);
+                tip_update = (d > tip_update || d != d) ? d : tip_update;       // NaN propagates as "not converged"
+              }
+            }
           }
           double hk[3];                                          // K/2: halving is exact
 #pragma unroll
@@ -828,6 +853,19 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
   }
 
+  if constexpr (EPI == EPI_QUAT) {
+    // One plain store per wave column and workgroup (same-address atomics from 8 XCDs cost ~200 ns each, and small
+    // operators have tens of thousands of tiles); the host takes the maximum of the few hundred partials it reads back.
+    if (p.partial != nullptr && wm == 0) {                       // the tip lanes of the wave are c == 0, g = 0..3
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const double other = __shfl_xor(tip_update, off);
+        tip_update = (other > tip_update || other != other) ? other : tip_update;
+      }
+      if (lane == 0) p.partial[blockIdx.x * WN + wn] = tip_update;
+    }
+  }
+
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
@@ -946,7 +984,8 @@ static int prepare_geometry(int dev) {
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
 template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
-static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream) {
+static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream,
+                  uint32_t* partials = nullptr) {
   const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
@@ -957,6 +996,10 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
+  if (partials != nullptr) {
+    if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
+    *partials = grid * G::WN;
+  }
   constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
   hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>), dim3(grid), dim3(G::THREADS), lds, stream, args);
   SRI_HIP(hipGetLastError());
@@ -964,21 +1007,21 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
 }
 
 template <class G>
-static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream) {
+static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0;
   if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
     if (args.nk >= 3) {
-      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream);
-      if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream);
+      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
+      if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
       return SRI_EUNSUPPORTED;                             // register-staged build: rows < 16, one chunk
     }
     if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {
-      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
-      if (dma) return launch<G, true, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
-      return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream);
+      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
+      if (dma) return launch<G, true, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
+      return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
     }
     return SRI_EUNSUPPORTED;
   }
@@ -1092,7 +1135,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
 }
 
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
-               hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr) {
+               hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr, uint32_t* partials = nullptr) {
   if (h == nullptr || (M > 0 && (dX == nullptr || dY == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
   if (M == 0) return SRI_OK;
   const bool rank1 = d_xb != nullptr;
@@ -1113,6 +1156,11 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.qe = quat ? quat->qe : nullptr;
   args.leg1 = quat ? quat->leg1 : nullptr;
   args.side_bufs = 0;   // set by launch()
+  args.tips_prev = quat ? quat->tips_prev : nullptr;
+  args.partial = quat ? quat->partial : nullptr;
+  args.stop = quat ? quat->stop : nullptr;
+  if (quat != nullptr && (quat->partial != nullptr) != (quat->tips_prev != nullptr)) return SRI_EINVAL;
+  if (quat != nullptr && quat->partial != nullptr && d_tips == nullptr) return SRI_EINVAL;
   args.ldx = ldx;
   args.ldy = ldy;
   args.m = M;
@@ -1129,16 +1177,19 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   const bool dma = h->rows >= 16;
   args.tail_k = h->rows % 16;
   h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);
-  if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream);
-  if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream);
-  return dispatch<GeoTall>(h, args, dma, rank1, stream);
+  if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
+  if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);
+  return dispatch<GeoTall>(h, args, dma, rank1, stream, partials);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
-                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream) {
+                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials) {
   if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
-  return run(h, dG, ldg, dG_next, ldn, M, d_x_base, static_cast<hipStream_t>(stream), d_tips, &quat);
+  if (quat.partial != nullptr && partials == nullptr) return SRI_EINVAL;
+  return run(h, dG, ldg, dG_next, ldn, M, d_x_base, static_cast<hipStream_t>(stream), d_tips, &quat, partials);
 }
+
+uint32_t max_partials(const sri_apply_t* h) { return h ? static_cast<uint32_t>(h->num_cus) * 8u * 4u : 0; }
 
 uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 0; }
 

@@ -28,9 +28,18 @@ void record_hip_error(int hip_error);
 struct QuatEpilogue {
   const double* qe;     // 9 per rod
   const double* leg1;
+  // optional convergence monitor: the launch writes partial[0 .. *partials) (one value per workgroup and wave column:
+  // the largest |tip - tips_prev| it saw, NaN if any); the caller takes the maximum
+  const double* tips_prev = nullptr;
+  double* partial = nullptr;
+  // optional: device word; the launch is a no-op when it is non-zero (lets a fixed-point loop be enqueued ahead of its
+  // own convergence test)
+  const unsigned long long* stop = nullptr;
 };
+// `partials`: in = capacity of quat.partial (entries), out = entries written by this launch.
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
-                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream);
+                        double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials = nullptr);
+uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------

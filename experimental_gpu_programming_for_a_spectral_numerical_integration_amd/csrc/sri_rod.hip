@@ -135,6 +135,51 @@ __global__ void max_abs_diff_kernel(uint32_t m, size_t cols, const double* __res
   }
 }
 
+// *out = max(*out, bits(max_i partial[i])) for the non-negative partial maxima of a fused step (NaN wins); one block
+__global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_t n, unsigned long long* out) {
+  double local = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double d = partial[i];
+    local = d > local || d != d ? d : local;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(local, off);
+    local = (other > local || other != other) ? other : local;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long bits = (local != local) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(local));
+    atomicMax(out, bits);
+  }
+}
+
+// Loop control of the device-driven Picard iteration; one block.  state = {stop, iterations, bits(update), -}.
+// Runs after every fused step: unless the loop has stopped, folds the step's partial maxima into `update`, counts the
+// iteration and raises stop = 1 (update <= tol) or 2 (iteration budget spent).  NaN compares false: runs to the budget.
+__global__ void picard_control_kernel(const double* __restrict__ partial, uint32_t n, double tol, unsigned long long max_iter,
+                                      unsigned long long* state) {
+  if (state[0] != 0ull) return;
+  __shared__ double wave_max[4];
+  double local = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double d = partial[i];
+    local = d > local || d != d ? d : local;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(local, off);
+    local = (other > local || other != other) ? other : local;
+  }
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) local = (wave_max[w] > local || wave_max[w] != wave_max[w]) ? wave_max[w] : local;
+    const unsigned long long it = state[1] + 1ull;
+    state[1] = it;
+    state[2] = static_cast<unsigned long long>(__double_as_longlong(local));
+    if (local <= tol) state[0] = 1ull;
+    else if (it >= max_iter) state[0] = 2ull;
+  }
+}
+
 }  // namespace sri
 
 // ------------------------------------------------------------------------------------------------
@@ -151,6 +196,9 @@ struct sri_rod_handle {
   double *d_K = nullptr, *d_G = nullptr, *d_Qa = nullptr, *d_B = nullptr, *d_xb4 = nullptr, *d_xb3 = nullptr;
   double* d_tips = nullptr;              // 2 x (4*rods): tip-node values of the last two iterates
   unsigned long long* d_diff = nullptr;   // two slots (ping-pong with the pipelined read-back)
+  double* d_partial = nullptr;            // cap_partial: per-workgroup tip-update maxima of the fused step
+  uint32_t cap_partial = 0;
+  unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
 };
 
 namespace sri {
@@ -218,7 +266,10 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
       hipMemcpy(h->d_nodes, x.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_leg, sizeof(double) * leg.size()) != hipSuccess ||
       hipMemcpy(h->d_leg, leg.data(), sizeof(double) * leg.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      (h->cap_partial = sri::max_partials(integ)) == 0 ||
+      hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial) != hipSuccess ||
+      hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess) {
     sri_rod_destroy(h);
     return SRI_ENOMEM;
   }
@@ -235,6 +286,8 @@ int sri_rod_destroy(sri_rod_t* h) {
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (h->d_diff) (void)hipFree(h->d_diff);
+  if (h->d_partial) (void)hipFree(h->d_partial);
+  if (h->d_state) (void)hipFree(h->d_state);
   delete h;
   return SRI_OK;
 }
@@ -266,13 +319,28 @@ int sri_rod_quaternion_rhs(sri_rod_t* h, const double* dK, size_t ldk, const dou
 }
 
 int sri_rod_quaternion_step(sri_rod_t* h, const double* d_qe, const double* dG, size_t ldg, const double* d_q_base, size_t rods,
-                            double* dG_next, size_t ldn, double* d_tips, void* stream) {
+                            double* dG_next, size_t ldn, double* d_tips, const double* d_tips_prev, uint64_t* d_update,
+                            void* stream) {
   if (h == nullptr || (rods > 0 && (d_qe == nullptr || dG == nullptr || d_q_base == nullptr || dG_next == nullptr)) || ldg < h->m ||
       ldn < h->m || dG == dG_next)
     return SRI_EINVAL;
+  if ((d_tips_prev != nullptr) != (d_update != nullptr) || (d_update != nullptr && d_tips == nullptr)) return SRI_EINVAL;
   if (rods == 0) return SRI_OK;
-  const sri::QuatEpilogue epi{d_qe, h->d_leg};
-  return sri::integrate_quat_step(h->integ, dG, ldg, d_q_base, epi, dG_next, ldn, 4 * rods, d_tips, stream);
+  sri::RodDeviceGuard guard;
+  int rc = guard.enter(h->device);
+  if (rc != SRI_OK) return rc;
+  sri::QuatEpilogue epi{d_qe, h->d_leg};
+  uint32_t partials = h->cap_partial;
+  if (d_update != nullptr) {
+    epi.tips_prev = d_tips_prev;
+    epi.partial = h->d_partial;
+  }
+  rc = sri::integrate_quat_step(h->integ, dG, ldg, d_q_base, epi, dG_next, ldn, 4 * rods, d_tips, stream, &partials);
+  if (rc != SRI_OK || d_update == nullptr) return rc;
+  hipLaunchKernelGGL(sri::fold_partials_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_partial, partials,
+                     reinterpret_cast<unsigned long long*>(d_update));
+  ROD_HIP(hipGetLastError());
+  return SRI_OK;
 }
 
 int sri_rod_position_rhs(sri_rod_t* h, const double* dQ, size_t ldq, size_t rods, double* dB, size_t ldb, void* stream) {
@@ -317,52 +385,56 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   if (rc != SRI_OK) return rc;
 
   // Fixed-point loop, one fused launch per iteration:  G^{k+1} = 1/2 A(K) Q^{k+1},  Q^{k+1} = Dnn^-1 G^k - w q0^T.
-  // Convergence is monitored on the TIP node of every column of Q — the Picard error of Q' = 1/2 A(K) Q grows with
-  // arc length, so the tip (node 0, X = 1) converges last — using the tip values the apply emits from its epilogue
-  // at no extra traffic.  The read-back is pipelined one iteration behind the launches so the device never idles
-  // on the host round trip; the price is at most one extra (harmless) iteration after convergence.
-  // Once the tips have settled, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
+  // DEVICE-DRIVEN: convergence is decided on the GPU.  Every fused step leaves the largest change of the TIP node of
+  // any column of Q in a small array (the Picard error of Q' = 1/2 A(K) Q grows with arc length, so the tip — node 0,
+  // X = 1 — converges last; the apply emits and compares the tip row in its epilogue at no extra traffic), a one-block
+  // control kernel folds it, counts the iteration and raises a stop word, and every later fused launch returns at once
+  // when that word is set.  The host therefore enqueues whole chunks of iterations without waiting, keeps two chunks in
+  // flight, and only reads back the 32-byte loop state per chunk: no host round trip sits between two iterations, and
+  // the launches enqueued past convergence cost a few microseconds each instead of an iteration.
+  // Once the loop has stopped, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
   // CONFIRMED on the whole panel:  max |1/2 A(K) Q - G|  bounds the next update of every entry of Q, because
-  // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with full-panel checks.
-  uint32_t it = 0;
-  double upd = INFINITY;
-  unsigned long long* h_bits = nullptr;
-  ROD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_bits), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
+  constexpr uint32_t kChunk = 8;                                // even: the ping-pong state of a chunk start repeats
+  double* bufs[2] = {cur, nxt};                                 // iteration k reads bufs[k & 1], writes bufs[(k + 1) & 1]
+  unsigned long long* h_state = nullptr;                        // 2 slots x 4 words, pinned
+  ROD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault));
   hipEvent_t done[2];
   ROD_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
   ROD_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
-  auto cleanup = [&]() { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); (void)hipHostFree(h_bits); };
-  bool full_checks = false;
-  // tips of Q^0: q_init in every column
+  auto cleanup = [&]() { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); (void)hipHostFree(h_state); };
+  // tips of Q^0 (what iteration 0 compares with): q_init in every column
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
                      qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
   ROD_HIP(hipGetLastError());
-  const sri::QuatEpilogue epi{d_qe, h->d_leg};
-  auto enqueue = [&](uint32_t k) -> int {
-    double* tips_new = h->d_tips + (k & 1) * cols;
-    double* tips_old = h->d_tips + ((k + 1) & 1) * cols;
-    int r = sri::integrate_quat_step(h->integ, cur, m, h->d_xb4, epi, nxt, m, cols, tips_new, stream);
-    if (r != SRI_OK) return r;
-    ROD_HIP(hipMemsetAsync(h->d_diff + (k & 1), 0, sizeof(unsigned long long), stream));
-    if (full_checks)
-      hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, static_cast<size_t>(m), cur,
-                         static_cast<size_t>(m), h->d_diff + (k & 1));
-    else
-      hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(256), dim3(256), 0, stream, 1u, cols, tips_new, static_cast<size_t>(1),
-                         tips_old, static_cast<size_t>(1), h->d_diff + (k & 1));
-    ROD_HIP(hipGetLastError());
-    ROD_HIP(hipMemcpyAsync(h_bits + (k & 1), h->d_diff + (k & 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    ROD_HIP(hipEventRecord(done[k & 1], stream));
-    std::swap(cur, nxt);
+  ROD_HIP(hipMemsetAsync(h->d_state, 0, 4 * sizeof(unsigned long long), stream));
+  double tip_tol = tol;
+  uint32_t enqueued = 0;                                        // iterations enqueued so far (k of the next one)
+  auto enqueue_chunk = [&](uint32_t slot) -> int {
+    for (uint32_t i = 0; i < kChunk; ++i, ++enqueued) {
+      const uint32_t k = enqueued;
+      sri::QuatEpilogue epi{d_qe, h->d_leg};
+      epi.tips_prev = h->d_tips + ((k + 1) & 1) * cols;
+      epi.partial = h->d_partial;
+      epi.stop = h->d_state;
+      uint32_t partials = h->cap_partial;
+      int r = sri::integrate_quat_step(h->integ, bufs[k & 1], m, h->d_xb4, epi, bufs[(k + 1) & 1], m, cols,
+                                       h->d_tips + (k & 1) * cols, stream, &partials);
+      if (r != SRI_OK) return r;
+      hipLaunchKernelGGL(sri::picard_control_kernel, dim3(1), dim3(256), 0, stream, h->d_partial, partials, tip_tol,
+                         static_cast<unsigned long long>(max_iter), h->d_state);
+      ROD_HIP(hipGetLastError());
+    }
+    ROD_HIP(hipMemcpyAsync(h_state + 4 * slot, h->d_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    ROD_HIP(hipEventRecord(done[slot], stream));
     return SRI_OK;
   };
-  auto harvest = [&](uint32_t k) -> int {        // update size of iteration k
-    ROD_HIP(hipEventSynchronize(done[k & 1]));
-    std::memcpy(&upd, h_bits + (k & 1), sizeof(double));
-    return SRI_OK;
-  };
+  uint32_t it = 0;
+  double upd = INFINITY;
   // Q from the newest right-hand side; then the bound on the next update over the whole panel -> upd
   auto finish = [&]() -> int {
+    cur = bufs[it & 1];
+    nxt = bufs[(it + 1) & 1];
     int r = sri_integrate(h->integ, cur, m, h->d_xb4, dQ, ldq, cols, stream);
     if (r != SRI_OK) return r;
     r = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, nxt, m, stream);
@@ -371,37 +443,35 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, static_cast<size_t>(m), cur,
                        static_cast<size_t>(m), h->d_diff);
     ROD_HIP(hipGetLastError());
-    ROD_HIP(hipMemcpyAsync(h_bits, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipStreamSynchronize(stream));
-    std::memcpy(&upd, h_bits, sizeof(double));
+    std::memcpy(&upd, h_state, sizeof(double));
     return SRI_OK;
   };
-  rc = enqueue(0);
-  it = 1;
-  bool finished = false;
   while (rc == SRI_OK) {
-    const bool more = it < max_iter;
-    if (more) {
-      rc = enqueue(it);
-      if (rc != SRI_OK) break;
-      ++it;
+    // two chunks in flight; the state read back after chunk `slot` tells whether the loop has stopped
+    uint32_t slot = 0;
+    rc = enqueue_chunk(0);
+    if (rc == SRI_OK) rc = enqueue_chunk(1);
+    unsigned long long stop = 0;
+    while (rc == SRI_OK) {
+      ROD_HIP(hipEventSynchronize(done[slot]));
+      stop = h_state[4 * slot];
+      it = static_cast<uint32_t>(h_state[4 * slot + 1]);
+      if (stop != 0) break;
+      rc = enqueue_chunk(slot);
+      slot ^= 1;
     }
-    rc = harvest(more ? it - 2 : it - 1);
     if (rc != SRI_OK) break;
-    if (upd <= tol) {                                       // NaN compares false: runs to max_iter
-      if (more) rc = harvest(it - 1);                       // the extra iteration in flight only tightens the result
-      if (rc != SRI_OK) break;
-      rc = finish();
-      finished = true;
-      if (rc != SRI_OK || upd <= tol) break;
-      full_checks = true;                                   // never observed; keep iterating with full-panel checks
-      finished = false;
-      if (it >= max_iter) break;
-      continue;
-    }
-    if (!more) break;
+    ROD_HIP(hipStreamSynchronize(stream));                       // the chunk still in flight is all no-ops
+    rc = finish();
+    if (rc != SRI_OK || upd <= tol || stop == 2 || it >= max_iter) break;
+    // tips settled but the panel has not (never observed): resume with a tighter tip criterion.  The no-op launches
+    // left the ping-pong state at iteration `it`.
+    tip_tol *= 0.25;
+    enqueued = it;
+    ROD_HIP(hipMemsetAsync(h->d_state, 0, sizeof(unsigned long long), stream));     // stop = 0, count and update kept
   }
-  if (rc == SRI_OK && !finished) rc = finish();             // iteration budget exhausted: still hand back the newest iterate
   cleanup();
   if (rc != SRI_OK) return rc;
   if (iters_out) *iters_out = it;

@@ -161,9 +161,12 @@ int sri_rod_quaternion_rhs(sri_rod_t *h, const double *dK, size_t ldk, const dou
  *     Q      = Dn_NN^-1 G - (Dn_NN^-1 Dn_IN) q_base^T        (the integration apply with its initial-value term)
  *     G_next = 1/2 A(K) Q,   K = Phi(X_i) qe                  (formed in the apply's store stage, no K / Q panel)
  * dG, dG_next: m x (4*rods) panels (must not alias); d_q_base: 4*rods doubles, the base quaternion of every column;
- * d_tips (optional, 4*rods): tip-node values of Q, for convergence monitoring. */
+ * d_tips (optional, 4*rods): tip-node values of Q, for convergence monitoring.  d_tips_prev + d_update (optional,
+ * both or neither; need d_tips): the launch also accumulates max_col |tip - tips_prev| into *d_update as
+ * max(*d_update, bits of that non-negative double) (NaN is stored as 0x7ff8000000000000); the caller zeroes it. */
 int sri_rod_quaternion_step(sri_rod_t *h, const double *d_qe, const double *dG, size_t ldg, const double *d_q_base,
-                            size_t rods, double *dG_next, size_t ldn, double *d_tips, void *hip_stream);
+                            size_t rods, double *dG_next, size_t ldn, double *d_tips, const double *d_tips_prev,
+                            uint64_t *d_update, void *hip_stream);
 
 /* b_i = R(q_i) e1, updatePositionb (main.cpp:121-140). */
 int sri_rod_position_rhs(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods, double *dB, size_t ldb,

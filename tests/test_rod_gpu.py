@@ -90,7 +90,9 @@ def test_fused_quaternion_step(sri, oracle, n, rods):
     rod = sri.RodIntegrator(n)
     dqe, dG, dq0 = (torch.from_numpy(a).cuda() for a in (qe, G, q0))
     tips = torch.full((rods, 4), float("nan"), dtype=torch.float64, device="cuda")
-    Gn = rod.quaternion_step(dqe, dG, dq0, tips=tips)
+    tips_prev = torch.from_numpy(rng.normal(size=(rods, 4))).cuda()
+    update = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    Gn = rod.quaternion_step(dqe, dG, dq0, tips=tips, tips_prev=tips_prev, update=update)
     # (a) unfused, same library
     integ = sri.SpectralApply(n, sri.OP_DNN_INV)
     Q = integ.integrate(dG.reshape(rods * 4, m), dq0.reshape(-1)).reshape(rods, 4, m)
@@ -98,6 +100,9 @@ def test_fused_quaternion_step(sri, oracle, n, rods):
     torch.cuda.synchronize()
     assert torch.equal(Gn, ref)
     assert torch.equal(tips, Q[:, :, 0])
+    # the in-kernel convergence monitor: bits of max |tip - previous tip|, exactly
+    assert update.view(torch.float64).item() == (tips - tips_prev).abs().max().item()
+    assert torch.equal(rod.quaternion_step(dqe, dG, dq0), ref)                 # without tips / monitor
     # (b) oracle matrices
     Dinv, Din = oracle.integration(n)
     w = Dinv @ Din
