@@ -176,8 +176,9 @@ int sri_rod_position_rhs(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods
  * fixed-point form Q <- Dn_NN^-1 (1/2 A(K) Q - Dn_IN q_init^T) on the MFMA integration apply (one fused launch per
  * iteration, sri_rod_quaternion_step), until the largest update of any entry is <= tol (or max_iter:
  * SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).  dQ: m x (4*rods).  *last_update: a bound on the
- * next update of any entry of Q, max |1/2 A(K) Q - G| over the panel (||Dn_NN^-1||_inf = 1).  Synchronises the
- * stream once per iteration (convergence read-back, pipelined one iteration behind the launches). */
+ * next update of any entry of Q, max |1/2 A(K) Q - G| over the panel (||Dn_NN^-1||_inf = 1).  The loop is driven
+ * on the device (tip-node monitor in the step's epilogue, a control kernel raising a stop word); the host waits on
+ * the stream once per chunk of 8 iterations and once at the end, so the stream must not be capturing. */
 int sri_rod_integrate_quaternions(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, double *dQ,
                                   size_t ldq, double tol, uint32_t max_iter, uint32_t *iters, double *last_update,
                                   void *hip_stream);
