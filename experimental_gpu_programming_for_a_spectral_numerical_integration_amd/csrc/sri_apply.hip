@@ -195,6 +195,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
   // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
+  // XOR swizzle of the 16-byte pieces of an X-image row by (column >> 1) & SWZ.  ds_read_b128 is served in four 16-lane
+  // groups ({0-3,12-15,20-27}, ...; tools/lds_bank_model.py): with the plain column order & 7 is conflict-free, with the
+  // permuted column order of EPI_QUAT it is 2-way (measured: SQ_LDS_BANK_CONFLICT = 0.5 x the X-read cycles) and & 6 is
+  // conflict-free instead.
+  constexpr int SWZ = EPI == EPI_QUAT ? 6 : 7;
   constexpr bool FOLD = RANK1 && (TAIL || !DMA);
   constexpr bool RANK1_EPI = RANK1 && !FOLD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
       for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
         const int cc = (wid + it * NW) * 8 + (lane >> 3);
-        const int piece = (lane & 7) ^ ((cc >> 1) & 7);
+        const int piece = (lane & 7) ^ ((cc >> 1) & SWZ);
         size_t col = col0_i + cc;
         col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
         xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int r = 0; r < XR; ++r) {
         const int idx = tid + r * G::THREADS;
         const int cc = idx / BK, k = idx % BK;
-        const int pos = (k >> 1) ^ ((cc >> 1) & 7);
+        const int pos = (k >> 1) ^ ((cc >> 1) & SWZ);
         *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (k & 1) * 8) = xreg[r];
       }
     }
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
   const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
-  const int sig = (cs >> 1) & 7;
+  const int sig = (cs >> 1) & SWZ;
   const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
 
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       double v = 0.0;
       if (col < p.m && kbase + kk < p.rows) v = p.x[col * p.ldx + kbase + kk];
       if constexpr (FOLD) { if (col < p.m && kbase + kk == p.rows) v = p.xb[col]; }
-      const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & 7);
+      const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & SWZ);
       *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

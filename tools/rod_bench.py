@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--rods", type=int, default=65536)
     ap.add_argument("--scale", type=float, default=2.0, help="qe ~ U[-scale, scale)")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline (profiling runs)")
     args = ap.parse_args()
     n, rods, m = args.n, args.rods, args.n - 1
     dev = torch.device("cuda", 0)
@@ -84,6 +85,8 @@ def main():
     }
     # CPU baseline: the oracle's restatement of main.cpp (dense per-rod solve), single thread, bounded sample
     try:
+        if args.no_cpu:
+            raise RuntimeError("skipped (--no-cpu)")
         import oracle
         qh = qe[:64].cpu().numpy()
         t0 = time.perf_counter(); done = 0

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--rods", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=400)
+    ap.add_argument("--ramp", type=float, default=1.0, help="seconds of clock ramp per variant")
     args = ap.parse_args()
     n, rods, m = args.n, args.rods, args.n - 1
     lib = sri.load_library()
@@ -41,11 +42,11 @@ def main():
             "apply": lambda: lib.sri_apply(integ._h, X.data_ptr(), ld, Y.data_ptr(), ld, cols, stream),
             "integrate": lambda: lib.sri_integrate(integ._h, X.data_ptr(), ld, xb.data_ptr(), Y.data_ptr(), ld, cols, stream),
             "fused_step": lambda: lib.sri_rod_quaternion_step(rod._h, qe.data_ptr(), X.data_ptr(), ld, xb.data_ptr(), rods,
-                                                              Y.data_ptr(), ld, None, stream),
+                                                              Y.data_ptr(), ld, None, None, None, stream),
         }
         for name, fn in calls.items():
             t0 = time.perf_counter()
-            while time.perf_counter() - t0 < 1.0:          # clock ramp on this very kernel
+            while time.perf_counter() - t0 < args.ramp:     # clock ramp on this very kernel
                 for _ in range(20):
                     assert fn() == 0
                 torch.cuda.synchronize()
