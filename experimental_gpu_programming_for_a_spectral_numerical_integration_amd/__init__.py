@@ -56,6 +56,7 @@ C_ABI = {
     "sri_rod_destroy": (_int, [_vp]),
     "sri_rod_strain_field": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "sri_rod_set_resident": (_int, [_vp, _int]),
     "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
@@ -320,6 +321,10 @@ class RodIntegrator:
         import torch
         return torch.cuda.current_stream(t.device).cuda_stream
 
+    def set_resident(self, enable: bool):
+        """Small grids (N <= 64, (N-1) % 16 != 0) use the on-chip one-launch pipeline; False forces the streaming path."""
+        _chk(load_library().sri_rod_set_resident(self._h, 1 if enable else 0), "sri_rod_set_resident")
+
     def _check_qe(self, qe):
         import torch
         if not (isinstance(qe, torch.Tensor) and qe.is_cuda and qe.dtype == torch.float64 and qe.is_contiguous()
@@ -385,8 +390,20 @@ class RodIntegrator:
         return R
 
     def integrate(self, qe, q_init=None, r_init=None, tol: float = 1e-14, max_iter: int = 200):
-        Q = self.integrate_quaternions(qe, q_init, tol, max_iter)
-        return Q, self.integrate_positions(Q, r_init)
+        """Quaternions and positions of every rod (sri_rod_integrate, main.cpp:197-201 batched): ``(Q, r)``."""
+        import torch
+        qe = self._check_qe(qe)
+        rods = qe.shape[0]
+        Q = torch.empty((rods, 4, self.m), dtype=torch.float64, device=qe.device)
+        R = torch.empty((rods, 3, self.m), dtype=torch.float64, device=qe.device)
+        qi = None if q_init is None else (C.c_double * 4)(*[float(v) for v in q_init])
+        ri = None if r_init is None else (C.c_double * 3)(*[float(v) for v in r_init])
+        it, upd = _u32(), C.c_double()
+        rc = load_library().sri_rod_integrate(self._h, qe.data_ptr(), rods, qi, ri, Q.data_ptr(), self.m, R.data_ptr(), self.m,
+                                              tol, max_iter, C.byref(it), C.byref(upd), self._stream(qe))
+        self.iterations, self.last_update = int(it.value), float(upd.value)
+        _chk(rc, "sri_rod_integrate")
+        return Q, R
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

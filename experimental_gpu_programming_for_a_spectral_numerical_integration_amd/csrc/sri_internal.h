@@ -42,6 +42,15 @@ int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const doub
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 
+// ---- on-chip rod pipeline for small grids (sri_rod_resident.hip, used by sri_rod.hip) -----------------------------
+struct ResidentRod;
+bool resident_supported(uint32_t m);                 // m = N - 1 <= 63 and m % 16 != 0
+int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out);   // `device` must be current
+int resident_destroy(ResidentRod* h);
+int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
+                       size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
+                       double* last_update_out, void* stream);
+
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------
 // One v_mfma_f64_16x16x4_f64 computes D[i][j] += sum_k P[i][k] Q[k][j] (i, j < 16, k < 4); lane l feeds
 // P[l & 15][l >> 4] and Q[l >> 4][l & 15] and receives D[(l >> 4) + 4*reg][l & 15], reg = 0..3.

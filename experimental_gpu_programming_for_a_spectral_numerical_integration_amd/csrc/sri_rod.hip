@@ -199,6 +199,8 @@ struct sri_rod_handle {
   double* d_partial = nullptr;            // cap_partial: per-workgroup tip-update maxima of the fused step
   uint32_t cap_partial = 0;
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
+  sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64, (N-1) % 16 != 0), else null
+  bool use_resident = true;
 };
 
 namespace sri {
@@ -273,7 +275,26 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
     sri_rod_destroy(h);
     return SRI_ENOMEM;
   }
+  if (sri::resident_supported(h->m)) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+      sri_rod_destroy(h);
+      return SRI_EHIP;
+    }
+    rc = sri::resident_create(n, device, prop.multiProcessorCount, &h->resident);
+    if (rc != SRI_OK) {
+      sri_rod_destroy(h);
+      return rc;
+    }
+  }
   *out = h;
+  return SRI_OK;
+}
+
+int sri_rod_set_resident(sri_rod_t* h, int enable) {
+  if (h == nullptr) return SRI_EINVAL;
+  if (enable && h->resident == nullptr) return SRI_EUNSUPPORTED;
+  h->use_resident = enable != 0;
   return SRI_OK;
 }
 
@@ -281,6 +302,7 @@ int sri_rod_destroy(sri_rod_t* h) {
   if (h == nullptr) return SRI_OK;
   sri::RodDeviceGuard guard;
   (void)guard.enter(h->device);
+  if (h->resident) sri::resident_destroy(h->resident);
   if (h->integ) sri_apply_destroy(h->integ);
   double* bufs[] = {h->d_nodes, h->d_leg, h->d_K, h->d_G, h->d_Qa, h->d_B, h->d_xb4, h->d_xb3, h->d_tips};
   for (double* b : bufs)
@@ -365,12 +387,15 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   sri::RodDeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
+  const double qi_default[4] = {1, 0, 0, 0};                 // main.cpp:106-107
+  const double* qi = q_init ? q_init : qi_default;
+  if (h->resident != nullptr && h->use_resident)             // small grid: the whole iteration on chip, one launch
+    return sri::resident_integrate(h->resident, d_qe, rods, qi, nullptr, dQ, ldq, nullptr, 0, tol, max_iter, iters_out,
+                                   last_update_out, stream_);
   rc = sri::ensure_workspace(h, rods);
   if (rc != SRI_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const uint32_t m = h->m;
-  const double qi_default[4] = {1, 0, 0, 0};                 // main.cpp:106-107
-  const double* qi = q_init ? q_init : qi_default;
   const size_t cols = 4 * rods;
 
   rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, m, stream);
@@ -504,6 +529,20 @@ int sri_rod_integrate_positions(sri_rod_t* h, const double* dQ, size_t ldq, size
 int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
                       size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
                       double* last_update_out, void* stream) {
+  if (h != nullptr && h->resident != nullptr && h->use_resident) {
+    // small grid: quaternions and positions in one launch, nothing but qe, Q and r crosses HBM
+    if ((rods > 0 && (d_qe == nullptr || dQ == nullptr || dR == nullptr)) || ldq < h->m || ldr < h->m || max_iter < 1 || !(tol >= 0.0))
+      return SRI_EINVAL;
+    if (iters_out) *iters_out = 0;
+    if (last_update_out) *last_update_out = 0.0;
+    if (rods == 0) return SRI_OK;
+    sri::RodDeviceGuard guard;
+    int rcg = guard.enter(h->device);
+    if (rcg != SRI_OK) return rcg;
+    const double qi_default[4] = {1, 0, 0, 0};
+    return sri::resident_integrate(h->resident, d_qe, rods, q_init ? q_init : qi_default, r_init, dQ, ldq, dR, ldr, tol, max_iter,
+                                   iters_out, last_update_out, stream);
+  }
   int rc = sri_rod_integrate_quaternions(h, d_qe, rods, q_init, dQ, ldq, tol, max_iter, iters_out, last_update_out, stream);
   if (rc != SRI_OK) return rc;
   return sri_rod_integrate_positions(h, dQ, ldq, rods, r_init, dR, ldr, stream);

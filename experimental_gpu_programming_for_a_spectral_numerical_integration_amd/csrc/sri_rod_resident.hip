@@ -1,0 +1,415 @@
+// sri_rod_resident.hip — the whole rod pipeline of main.cpp:197-201 in ONE launch for small grids (N <= 64).
+//
+// For N - 1 = m <= 63 unknown nodes a rod's entire state fits on chip: the integration matrix Dn_NN^-1 (at most
+// 32 KiB packed) lives in LDS for the workgroup, and every wave keeps the right-hand-side panel of ITS rods
+// (4 columns per rod, K = 16*TM doubles per column) in its own LDS image.  A wave then runs the complete fixed-point
+// iteration of the quaternion system (sri_rod.hip has the maths; same linear system as main.cpp:91-118)
+//       G <- 1/2 A(K) (Dn_NN^-1 G - w q0^T)
+// with v_mfma_f64_16x16x4_f64 reading X fragments from that image and writing the next right-hand side back into it,
+// until max |G_new - G_old| <= tol — a bound on the next update of every entry of Q because ||Dn_NN^-1||_inf = 1
+//  — then forms Q, the position right-hand side b = R(q) e1 (main.cpp:121-140) and
+// r = Dn_NN^-1 b - w r0^T (main.cpp:145-176) the same way.  HBM sees 72 bytes of strain coefficients per rod coming in
+// and the Q / r panels going out: nothing per iteration, no launch per iteration, no host round trip.
+//
+// Conventions shared with sri_apply.hip (see sri_internal.h): the X fragment is the MFMA's first operand, so a tile is
+// accumulated transposed (lane (c, g) = (lane & 15, lane >> 4) holds row c of columns g, g+4, g+8, g+12); the column
+// fed as MFMA column t is image column 4*(t&3) + (t>>2), so that those four registers are (w, x, y, z) of ONE rod at
+// one node and 1/2 A(K) q is in-lane arithmetic; the 16-byte pieces of an image row are XOR-swizzled by
+// (column >> 1) & 6 (conflict-free ds_read_b128 for that column order, tools/lds_bank_model.py); the initial-value term
+// rides in the product: the host packs -w = -Dn_NN^-1 Dn_IN as operator column k = m and the image holds the base
+// value of every column in slot k = m (needs a free slot: m % 16 != 0; other sizes use the streaming path).
+// Waves of a workgroup share only the read-only operator: after one barrier they run independently.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define SRI_DEVICE_HELPERS 1
+#include "sri_internal.h"
+
+namespace sri {
+
+typedef double rd2 __attribute__((ext_vector_type(2)));
+typedef double rd4 __attribute__((ext_vector_type(4)));
+
+#define RES_HIP(call)                                            \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) {                                     \
+      sri::record_hip_error(static_cast<int>(e__));              \
+      (void)hipGetLastError();                                   \
+      return SRI_EHIP;                                           \
+    }                                                            \
+  } while (0)
+
+struct ResidentArgs {
+  const double* apack;     // [k chunk][row tile][k pair][lane][2], -w folded in as column k = m
+  const double* p1;        // P1 = 2X - 1 at the unknown nodes, zero padded to 16*TM
+  const double* qe;        // 9 per rod
+  double* Q;               // m x (4*rods)
+  double* R;               // m x (3*rods) or null (quaternions only)
+  double* stats;           // 2 per workgroup: {most iterations of any wave, largest final update (NaN if any)}
+  size_t rods, ldq, ldr;
+  double q0[4], r0[3];
+  double tol;
+  uint32_t m, max_iter;
+};
+
+// TM row tiles (m <= 16*TM - 1), TN column tiles of 16 columns = 4 rods per wave task, NW waves per workgroup.
+template <int TM, int TN, int NW>
+struct ResGeo {
+  static constexpr int A_BYTES = TM * TM * 2048;
+  static constexpr int CHUNK_BYTES = TN * 16 * 128;            // one k chunk of a wave's image
+  static constexpr int IMG_BYTES = TM * CHUNK_BYTES;
+  static constexpr int LDS_BYTES = A_BYTES + NW * IMG_BYTES + NW * 16;
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int RODS_PER_TASK = 4 * TN;
+  static_assert(LDS_BYTES <= 160 * 1024, "operator + wave images exceed a CU");
+};
+
+template <int TM, int TN, int NW>
+__global__ __launch_bounds__(64 * NW) void rod_resident_kernel(const ResidentArgs p) {
+  using G = ResGeo<TM, TN, NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+
+  // operator -> LDS, once per workgroup (the packed layout is the read layout: a linear copy)
+  for (int i = tid; i < G::A_BYTES / 16; i += G::THREADS)
+    reinterpret_cast<rd2*>(smem)[i] = reinterpret_cast<const rd2*>(p.apack)[i];
+  __syncthreads();
+
+  char* img = smem + G::A_BYTES + wid * G::IMG_BYTES;
+  const int cs = 4 * (c & 3) + (c >> 2);                       // image column fed as MFMA column c
+  // byte offset, inside a k chunk of the image, of the fragment this lane reads for column tile tn, k pair j
+  auto frag_off = [&](int tn, int j) __attribute__((always_inline)) {
+    const int col = tn * 16 + cs;
+    return col * 128 + (((4 * j + g) ^ ((col >> 1) & 6)) << 4);
+  };
+  // ... and of element (k = c of chunk tm) of column `col`, which this lane writes
+  auto elem_off = [&](int col) __attribute__((always_inline)) {
+    return col * 128 + ((((c >> 1)) ^ ((col >> 1) & 6)) << 4) + (c & 1) * 8;
+  };
+
+  double p1[TM], p2[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    p1[tm] = p.p1[tm * 16 + c];
+    p2[tm] = ((2 * 1 + 1) * p1[tm] * p1[tm] - 1 * 1.0) / (1 + 1);            // as strain_kernel (sri_rod.hip)
+  }
+
+  const size_t ntasks = (p.rods + G::RODS_PER_TASK - 1) / G::RODS_PER_TASK;
+  uint32_t worst_it = 0;
+  double worst_upd = 0.0;
+
+  // Y = A * image for this wave's columns: acc[tm][tn][r] = Y[16 tm + c][16 tn + 4 g + r]
+  rd4 acc[TM][TN];
+  auto product = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = rd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc < TM; ++kc)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rd2 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          a[tm] = *reinterpret_cast<const rd2*>(smem + ((kc * TM + tm) * 2 + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + kc * G::CHUNK_BYTES + frag_off(tn, j));
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+      }
+  };
+  auto wave_max = [&](double v) __attribute__((always_inline)) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double other = __shfl_xor(v, off);
+      v = (other > v || other != other) ? other : v;             // NaN wins
+    }
+    return v;
+  };
+
+  for (size_t task = static_cast<size_t>(blockIdx.x) * NW + wid; task < ntasks; task += static_cast<size_t>(gridDim.x) * NW) {
+    const size_t rod0 = task * G::RODS_PER_TASK + g;              // this lane's rod in column tile tn is rod0 + 4 tn
+    // K/2 at this lane's (row, rod) pairs — invariant over the iteration
+    double hk[TM][TN][3];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      size_t rod = rod0 + 4 * tn;
+      rod = rod < p.rods ? rod : p.rods - 1;                      // tail task: recompute a valid rod, never store it
+      const double* q = p.qe + rod * 9;
+      double q9[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q9[i] = q[i];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double s = q9[a * 3 + 0];
+          s = s + p1[tm] * q9[a * 3 + 1];
+          s = s + p2[tm] * q9[a * 3 + 2];
+          hk[tm][tn][a] = 0.5 * s;
+        }
+    }
+    // image <- G^0 = 1/2 A(K) q0 at the unknown nodes; slot k = m <- q0 (the base value of every column); rest 0
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const uint32_t row = tm * 16 + c;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        double gq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (row < p.m) quat_rhs_half(hk[tm][tn][0], hk[tm][tn][1], hk[tm][tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = row < p.m ? gq[r] : (row == p.m ? p.q0[r] : 0.0);
+          *reinterpret_cast<double*>(img + tm * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r)) = v;
+        }
+      }
+    }
+
+    // ---- fixed point ------------------------------------------------------------------------------
+    uint32_t it = 0;
+    double upd = INFINITY;
+    while (it < p.max_iter) {
+      product();                                                  // acc = Q^{it+1} (initial-value term included)
+      double local = 0.0;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const uint32_t row = tm * 16 + c;
+        if (row < p.m) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            double gq[4];
+            quat_rhs_half(hk[tm][tn][0], hk[tm][tn][1], hk[tm][tn][2], acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2],
+                          acc[tm][tn][3], gq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              double* slot = reinterpret_cast<double*>(img + tm * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r));
+              const double d = fabs(gq[r] - *slot);
+              local = (d > local || d != d) ? d : local;
+              *slot = gq[r];
+            }
+          }
+        }
+      }
+      ++it;
+      upd = wave_max(local);
+      if (upd <= p.tol) break;                                    // wave-uniform; NaN compares false
+    }
+    worst_it = it > worst_it ? it : worst_it;
+    worst_upd = (upd > worst_upd || upd != upd) ? upd : worst_upd;
+
+    // ---- Q = Dn_NN^-1 G - w q0^T, stored; then b = R(q) e1 into the image (4th column of a rod: 0) -------------
+    product();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const uint32_t row = tm * 16 + c;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const size_t rod = rod0 + 4 * tn;
+        const double w = acc[tm][tn][0], x = acc[tm][tn][1], y = acc[tm][tn][2], z = acc[tm][tn][3];
+        if (row < p.m && rod < p.rods) {
+          double* qc = p.Q + rod * 4 * p.ldq + row;
+          qc[0] = w; qc[p.ldq] = x; qc[2 * p.ldq] = y; qc[3 * p.ldq] = z;
+        }
+        if (p.R != nullptr) {
+          // main.cpp:136 q.toRotationMatrix() * e1 (Eigen: no normalisation), as position_rhs_kernel (sri_rod.hip)
+          const double ty = 2 * y, tz = 2 * z;
+          const double twy = ty * w, twz = tz * w, txy = ty * x, txz = tz * x, tyy = ty * y, tzz = tz * z;
+          const double b[4] = {1 - (tyy + tzz), txy + twz, txz - twy, 0.0};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = row < p.m ? b[r] : (row == p.m && r < 3 ? p.r0[r] : 0.0);
+            *reinterpret_cast<double*>(img + tm * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r)) = v;
+          }
+        }
+      }
+    }
+    if (p.R != nullptr) {
+      product();                                                  // r = Dn_NN^-1 b - w r0^T  (main.cpp:172)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const uint32_t row = tm * 16 + c;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const size_t rod = rod0 + 4 * tn;
+          if (row < p.m && rod < p.rods) {
+            double* rc = p.R + rod * 3 * p.ldr + row;
+            rc[0] = acc[tm][tn][0]; rc[p.ldr] = acc[tm][tn][1]; rc[2 * p.ldr] = acc[tm][tn][2];
+          }
+        }
+      }
+    }
+  }
+
+  // per-workgroup statistics (every wave arrives here: the task loop has no barrier inside)
+  double* wstat = reinterpret_cast<double*>(smem + G::A_BYTES + NW * G::IMG_BYTES);
+  if (lane == 0) {
+    wstat[2 * wid] = static_cast<double>(worst_it);
+    wstat[2 * wid + 1] = worst_upd;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double its = 0.0, u = 0.0;
+    for (int w = 0; w < NW; ++w) {
+      its = wstat[2 * w] > its ? wstat[2 * w] : its;
+      const double v = wstat[2 * w + 1];
+      u = (v > u || v != v) ? v : u;
+    }
+    p.stats[2 * blockIdx.x] = its;
+    p.stats[2 * blockIdx.x + 1] = u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct ResidentRod {
+  int device = 0;
+  uint32_t n = 0, m = 0;
+  int tm = 0;
+  int num_cus = 0;
+  double* d_apack = nullptr;
+  double* d_p1 = nullptr;
+  double* d_stats = nullptr;
+  double* h_stats = nullptr;      // pinned
+  uint32_t cap_blocks = 0;
+};
+
+bool resident_supported(uint32_t m) { return m >= 2 && m <= 63 && m % 16 != 0; }
+
+template <int TM, int TN, int NW>
+static int resident_launch(ResidentRod* h, ResidentArgs args, hipStream_t stream, uint32_t* blocks_out) {
+  using G = ResGeo<TM, TN, NW>;
+  const auto kern = &rod_resident_kernel<TM, TN, NW>;
+  static bool prepared[16] = {};
+  static int per_cu[16] = {};
+  if (h->device < 0 || h->device >= 16) return SRI_EUNSUPPORTED;
+  if (!prepared[h->device]) {
+    RES_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    int nb = 0;
+    RES_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
+    per_cu[h->device] = nb < 1 ? 1 : nb;
+    prepared[h->device] = true;
+  }
+  const size_t ntasks = (args.rods + G::RODS_PER_TASK - 1) / G::RODS_PER_TASK;
+  const size_t wgs_needed = (ntasks + NW - 1) / NW;
+  size_t grid = static_cast<size_t>(h->num_cus) * per_cu[h->device];
+  grid = wgs_needed < grid ? wgs_needed : grid;
+  if (grid > h->cap_blocks) return SRI_EUNSUPPORTED;
+  *blocks_out = static_cast<uint32_t>(grid);
+  hipLaunchKernelGGL((rod_resident_kernel<TM, TN, NW>), dim3(static_cast<unsigned>(grid)), dim3(G::THREADS), G::LDS_BYTES, stream, args);
+  RES_HIP(hipGetLastError());
+  return SRI_OK;
+}
+
+int resident_destroy(ResidentRod* h) {
+  if (h == nullptr) return SRI_OK;
+  if (h->d_apack) (void)hipFree(h->d_apack);
+  if (h->d_p1) (void)hipFree(h->d_p1);
+  if (h->d_stats) (void)hipFree(h->d_stats);
+  if (h->h_stats) (void)hipHostFree(h->h_stats);
+  delete h;
+  return SRI_OK;
+}
+
+// Caller has made `device` current.
+int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out) {
+  *out = nullptr;
+  const uint32_t m = n - 1;
+  if (!resident_supported(m)) return SRI_EUNSUPPORTED;
+  ResidentRod* h = new (std::nothrow) ResidentRod();
+  if (h == nullptr) return SRI_ENOMEM;
+  h->device = device;
+  h->n = n;
+  h->m = m;
+  h->tm = static_cast<int>(m / 16 + 1);
+  h->num_cus = num_cus;
+  const int TM = h->tm;
+  std::vector<double> A(static_cast<size_t>(m) * m), Din(m), w(m, 0.0), x(n);
+  int rc = cheb_integration(n, A.data(), m, Din.data());
+  if (rc != SRI_OK) { delete h; return rc; }
+  for (uint32_t k = 0; k < m; ++k)
+    for (uint32_t i = 0; i < m; ++i) w[i] = w[i] + A[i + static_cast<size_t>(k) * m] * Din[k];   // as sri_apply_create
+  cheb_points(n, 1.0, x.data());
+  std::vector<double> packed(static_cast<size_t>(TM) * TM * 256, 0.0), p1(static_cast<size_t>(TM) * 16, 0.0);
+  size_t o = 0;
+  for (int kc = 0; kc < TM; ++kc)
+    for (int tm = 0; tm < TM; ++tm)
+      for (int j = 0; j < 2; ++j)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 2; ++e, ++o) {
+            const uint32_t row = tm * 16 + (l & 15);
+            const uint32_t k = kc * 16 + k_of(j, l >> 4, e);
+            if (row < m && k < m) packed[o] = A[row + static_cast<size_t>(k) * m];
+            else if (row < m && k == m) packed[o] = -w[row];
+          }
+  for (uint32_t i = 0; i < m; ++i) p1[i] = (2 * x[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+  h->cap_blocks = static_cast<uint32_t>(num_cus) * 16u;
+  auto fail = [&](int code) { resident_destroy(h); return code; };
+  if (hipMalloc(&h->d_apack, packed.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+  if (hipMalloc(&h->d_p1, p1.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+  if (hipMalloc(&h->d_stats, 2 * sizeof(double) * h->cap_blocks) != hipSuccess) return fail(SRI_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), 2 * sizeof(double) * h->cap_blocks, hipHostMallocDefault) != hipSuccess)
+    return fail(SRI_ENOMEM);
+  if (hipMemcpy(h->d_apack, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+  if (hipMemcpy(h->d_p1, p1.data(), p1.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+  *out = h;
+  return SRI_OK;
+}
+
+// Quaternions (dR == nullptr) or quaternions + positions of `rods` rods; synchronises the stream once (statistics).
+int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
+                       size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
+                       double* last_update_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ResidentArgs args;
+  args.apack = h->d_apack;
+  args.p1 = h->d_p1;
+  args.qe = d_qe;
+  args.Q = dQ;
+  args.R = dR;
+  args.stats = h->d_stats;
+  args.rods = rods;
+  args.ldq = ldq;
+  args.ldr = ldr;
+  for (int i = 0; i < 4; ++i) args.q0[i] = q_init[i];
+  for (int i = 0; i < 3; ++i) args.r0[i] = r_init ? r_init[i] : 0.0;
+  args.tol = tol;
+  args.m = h->m;
+  args.max_iter = max_iter;
+  uint32_t blocks = 0;
+  int rc;
+  switch (h->tm) {
+    case 1: rc = resident_launch<1, 4, 4>(h, args, stream, &blocks); break;    // 16 rods per wave, 34 KiB: several WG per CU
+    case 2: rc = resident_launch<2, 4, 4>(h, args, stream, &blocks); break;    // 72 KiB: 2 WG per CU
+    case 3: rc = resident_launch<3, 2, 8>(h, args, stream, &blocks); break;    // 114 KiB: 1 WG (8 waves) per CU
+    default: rc = resident_launch<4, 1, 8>(h, args, stream, &blocks); break;   //  96 KiB: 1 WG (8 waves) per CU
+  }
+  if (rc != SRI_OK) return rc;
+  RES_HIP(hipMemcpyAsync(h->h_stats, h->d_stats, 2 * sizeof(double) * blocks, hipMemcpyDeviceToHost, stream));
+  RES_HIP(hipStreamSynchronize(stream));
+  double its = 0.0, upd = 0.0;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    its = h->h_stats[2 * b] > its ? h->h_stats[2 * b] : its;
+    const double v = h->h_stats[2 * b + 1];
+    upd = (v > upd || v != v) ? v : upd;
+  }
+  if (iters_out) *iters_out = static_cast<uint32_t>(its);
+  if (last_update_out) *last_update_out = upd;
+  return (upd <= tol) ? SRI_OK : SRI_ENOTCONVERGED;
+}
+
+}  // namespace sri

@@ -149,6 +149,11 @@ typedef struct sri_rod_handle sri_rod_t;
 int sri_rod_create(sri_rod_t **out, uint32_t n, int device);
 int sri_rod_destroy(sri_rod_t *h);
 
+/* Small grids (N <= 64 with (N-1) % 16 != 0: N = 16, 32, 64, ...) are integrated by an on-chip kernel: one launch
+ * runs the whole fixed point (and the position step) with the rod state resident in LDS.  enable = 0 forces the
+ * streaming path (one fused launch per iteration) that larger grids use; SRI_EUNSUPPORTED if enabling is impossible. */
+int sri_rod_set_resident(sri_rod_t *h, int enable);
+
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):
  * d_qe: 9 doubles per rod in main.cpp:187-195 order; dK: m x (3*rods), ldk >= m. */
 int sri_rod_strain_field(sri_rod_t *h, const double *d_qe, size_t rods, double *dK, size_t ldk, void *hip_stream);

@@ -18,11 +18,14 @@ def _oracle_rods(oracle, n, qe, q_init=None, r_init=None):
     return Q, R
 
 
-def test_config1_rod_of_main_cpp(sri, oracle):
-    """BASELINE config 1 entirely on the device: N=16, the hard-coded qe of main.cpp:187-195."""
+@pytest.mark.parametrize("resident", [True, False])
+def test_config1_rod_of_main_cpp(sri, oracle, resident):
+    """BASELINE config 1 entirely on the device: N=16, the hard-coded qe of main.cpp:187-195 — by the on-chip
+    one-launch pipeline (resident) and by the streaming path (one fused launch per iteration)."""
     import torch
 
     rod = sri.RodIntegrator(16)
+    rod.set_resident(resident)
     qe = torch.from_numpy(oracle.QE_MAIN_CPP[None, :].copy()).cuda()
     Q, R = rod.integrate(qe)
     torch.cuda.synchronize()
@@ -34,12 +37,14 @@ def test_config1_rod_of_main_cpp(sri, oracle):
     assert abs(Q[0, 0, 0].item() - 0.7997698672530426) <= 1e-13 and abs(R[0, 2, 0].item() + 0.74591365968166945) <= 1e-13
 
 
-@pytest.mark.parametrize("n,rods", [(16, 64), (64, 12), (32, 33)])
-def test_batched_rods_match_oracle(sri, oracle, n, rods):
+@pytest.mark.parametrize("resident", [True, False])
+@pytest.mark.parametrize("n,rods", [(16, 64), (64, 12), (32, 33), (48, 70), (10, 5), (20, 129)])
+def test_batched_rods_match_oracle(sri, oracle, n, rods, resident):
     import torch
 
     qe = _qe_batch(rods)
     rod = sri.RodIntegrator(n)
+    rod.set_resident(resident)
     dqe = torch.from_numpy(qe).cuda()
     # strain field and RHS builders are bit-identical to the oracle's arithmetic
     K = rod.strain_field(dqe).cpu().numpy()
@@ -140,10 +145,36 @@ def test_large_batch_properties(sri):
     assert (Qp[:, 2, 0] - torch.sin(theta_tip / 2)).abs().max().item() <= 1e-12
 
 
-def test_not_converged_is_reported(sri):
+def test_resident_and_streaming_paths_agree(sri):
+    """N=64, 3000 rods (ragged last wave task): the on-chip pipeline against the streaming one, no oracle involved;
+    and the resident path is refused where it cannot exist."""
+    import torch
+
+    qe = torch.from_numpy(_qe_batch(3000, seed=11)).cuda()
+    rod = sri.RodIntegrator(64)
+    Qa, Ra = rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
+    it_res = rod.iterations
+    Qq = rod.integrate_quaternions(qe, q_init=[0.6, 0.0, 0.8, 0.0])
+    assert torch.equal(Qq, Qa)                                   # quaternion-only entry point, same kernel
+    rod.set_resident(False)
+    Qb, Rb = rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
+    torch.cuda.synchronize()
+    assert (Qa - Qb).abs().max().item() <= 1e-13 and (Ra - Rb).abs().max().item() <= 1e-13
+    assert abs(it_res - rod.iterations) <= 3
+    for n in (17, 65, 256):                                      # (N-1) % 16 == 0, or too large
+        big = sri.RodIntegrator(n)
+        with pytest.raises(sri.SriError) as e:
+            big.set_resident(True)
+        assert e.value.status == -6
+        big.set_resident(False)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_not_converged_is_reported(sri, resident):
     import torch
 
     rod = sri.RodIntegrator(16)
+    rod.set_resident(resident)
     qe = torch.from_numpy(_qe_batch(3, scale=2.0)).cuda()
     with pytest.raises(sri.SriError) as e:
         rod.integrate_quaternions(qe, max_iter=2)
