@@ -179,3 +179,20 @@ def test_not_converged_is_reported(sri, resident):
     with pytest.raises(sri.SriError) as e:
         rod.integrate_quaternions(qe, max_iter=2)
     assert e.value.status == -7 and rod.iterations == 2 and rod.last_update > 1e-8
+
+
+@pytest.mark.parametrize("n,resident", [(16, True), (16, False), (64, True), (80, False)])
+def test_nan_strain_is_reported_not_hidden(sri, n, resident):
+    """A NaN in one rod's strain coefficients must surface as 'not converged' (NaN compares false against tol all the
+    way through the device-side monitors), never as a silently converged batch."""
+    import math
+    import torch
+
+    qe = torch.from_numpy(_qe_batch(40, seed=3, scale=1.0)).cuda()
+    qe[17, 4] = float("nan")
+    rod = sri.RodIntegrator(n)
+    if n <= 64:
+        rod.set_resident(resident)
+    with pytest.raises(sri.SriError) as e:
+        rod.integrate(qe, max_iter=40)
+    assert e.value.status == -7 and rod.iterations == 40 and math.isnan(rod.last_update)
