@@ -57,6 +57,7 @@ C_ABI = {
     "sri_rod_strain_field": (_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_set_resident": (_int, [_vp, _int]),
+    "sri_rod_set_predictor": (_int, [_vp, _int]),
     "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
@@ -324,6 +325,10 @@ class RodIntegrator:
     def set_resident(self, enable: bool):
         """Small grids (N <= 64, (N-1) % 16 != 0) use the on-chip one-launch pipeline; False forces the streaming path."""
         _chk(load_library().sri_rod_set_resident(self._h, 1 if enable else 0), "sri_rod_set_resident")
+
+    def set_predictor(self, enable: bool):
+        """Large grids (N > 64) start the fixed point from an interpolated 32-node solution; False starts from q_init."""
+        _chk(load_library().sri_rod_set_predictor(self._h, 1 if enable else 0), "sri_rod_set_predictor")
 
     def _check_qe(self, qe):
         import torch

@@ -152,6 +152,65 @@ __global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_
   }
 }
 
+// Coarse-to-fine start of the fixed point ("nested iteration"): the quaternions solved on a coarse Chebyshev grid
+// (Nc nodes, on-chip pipeline) are interpolated to the fine unknown nodes by the barycentric matrix P — the base node
+// X = 0 is a coarse node too and carries q0 — and turned into the first right-hand side G^0 = 1/2 A(K) Q^0.
+//   Qc: mc x (4*rods) coarse panel;  PT: (mc+1) x m, PT[j*m + i] = P[i][j];  G: m x (4*rods);  tips: 4*rods (row 0 of Q^0).
+// One thread per fine node keeps its row of P in registers and walks kProlongRods rods whose coarse values sit in LDS.
+constexpr int kProlongRods = 16;
+constexpr int kCoarseN = 32;
+__global__ __launch_bounds__(256) void prolong_rhs_kernel(uint32_t m, size_t rods, const double* __restrict__ Qc, size_t ldc,
+                                                          const double* __restrict__ PT, double q0w, double q0x, double q0y, double q0z,
+                                                          const double* __restrict__ qe, const double* __restrict__ nodes,
+                                                          double* __restrict__ G, size_t ldg, double* __restrict__ tips) {
+  constexpr int MC = kCoarseN - 1;
+  __shared__ double qc[kProlongRods][4][MC];
+  __shared__ double qes[kProlongRods][9];
+  const size_t rod0 = static_cast<size_t>(blockIdx.x) * kProlongRods;
+  const uint32_t i = blockIdx.y * blockDim.x + threadIdx.x;
+  const uint32_t nr = static_cast<uint32_t>(rods - rod0 < static_cast<size_t>(kProlongRods) ? rods - rod0 : kProlongRods);
+  for (uint32_t t = threadIdx.x; t < nr * 4 * MC; t += blockDim.x) {
+    const uint32_t r = t / (4 * MC), c = (t / MC) % 4, j = t % MC;
+    qc[r][c][j] = Qc[((rod0 + r) * 4 + c) * ldc + j];
+  }
+  for (uint32_t t = threadIdx.x; t < nr * 9; t += blockDim.x) qes[t / 9][t % 9] = qe[(rod0 + t / 9) * 9 + t % 9];
+  __syncthreads();
+  if (i >= m) return;
+  double prow[kCoarseN];
+#pragma unroll
+  for (int j = 0; j < kCoarseN; ++j) prow[j] = PT[static_cast<size_t>(j) * m + i];
+  const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+  const double P1 = x, P2 = ((2 * 1 + 1) * x * P1 - 1 * 1.0) / (1 + 1);     // as strain_kernel
+  const double q0[4] = {q0w, q0x, q0y, q0z};
+  for (uint32_t r = 0; r < nr; ++r) {
+    double q[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double s = prow[MC] * q0[c];
+#pragma unroll
+      for (int j = 0; j < MC; ++j) s = __builtin_fma(prow[j], qc[r][c][j], s);
+      q[c] = s;
+    }
+    double hk[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double s = qes[r][a * 3 + 0];
+      s = s + P1 * qes[r][a * 3 + 1];
+      s = s + P2 * qes[r][a * 3 + 2];
+      hk[a] = 0.5 * s;
+    }
+    double gq[4];
+    quat_rhs_half(hk[0], hk[1], hk[2], q[0], q[1], q[2], q[3], gq);
+    const size_t col = (rod0 + r) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) G[(col + c) * ldg + i] = gq[c];
+    if (i == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tips[col + c] = q[c];
+    }
+  }
+}
+
 // Loop control of the device-driven Picard iteration; one block.  state = {stop, iterations, bits(update), -}.
 // Runs after every fused step: unless the loop has stopped, folds the step's partial maxima into `update`, counts the
 // iteration and raises stop = 1 (update <= tol) or 2 (iteration budget spent).  NaN compares false: runs to the budget.
@@ -201,6 +260,9 @@ struct sri_rod_handle {
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
   sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64, (N-1) % 16 != 0), else null
   bool use_resident = true;
+  sri::ResidentRod* coarse = nullptr;     // N > 64: on-chip solver on a 32-node grid, predictor of the fine fixed point
+  double* d_PT = nullptr;                 // its barycentric interpolation matrix to the fine unknown nodes, transposed
+  bool use_predictor = true;
 };
 
 namespace sri {
@@ -275,19 +337,54 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
     sri_rod_destroy(h);
     return SRI_ENOMEM;
   }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    sri_rod_destroy(h);
+    return SRI_EHIP;
+  }
   if (sri::resident_supported(h->m)) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-      sri_rod_destroy(h);
-      return SRI_EHIP;
-    }
     rc = sri::resident_create(n, device, prop.multiProcessorCount, &h->resident);
     if (rc != SRI_OK) {
       sri_rod_destroy(h);
       return rc;
     }
+  } else if (n > 64) {
+    // predictor: the same rods on a 32-node grid (on chip) + barycentric interpolation to the fine unknown nodes.
+    // Chebyshev-Lobatto weights (-1)^j, halved at both ends; P[i][j] = (w_j / (x_i - xc_j)) / sum_l (w_l / (x_i - xc_l)).
+    rc = sri::resident_create(sri::kCoarseN, device, prop.multiProcessorCount, &h->coarse);
+    if (rc != SRI_OK) {
+      sri_rod_destroy(h);
+      return rc;
+    }
+    std::vector<double> xc(sri::kCoarseN), PT(static_cast<size_t>(sri::kCoarseN) * h->m, 0.0);
+    sri::cheb_points(sri::kCoarseN, 1.0, xc.data());
+    for (uint32_t i = 0; i < h->m; ++i) {
+      int hit = -1;
+      long double denom = 0.0L, t[sri::kCoarseN];
+      for (int j = 0; j < sri::kCoarseN; ++j) {
+        const long double d = static_cast<long double>(x[i]) - static_cast<long double>(xc[j]);
+        if (d == 0.0L) { hit = j; break; }
+        const long double wj = ((j & 1) ? -1.0L : 1.0L) * ((j == 0 || j == sri::kCoarseN - 1) ? 0.5L : 1.0L);
+        t[j] = wj / d;
+        denom += t[j];
+      }
+      for (int j = 0; j < sri::kCoarseN; ++j)
+        PT[static_cast<size_t>(j) * h->m + i] = hit >= 0 ? (j == hit ? 1.0 : 0.0) : static_cast<double>(t[j] / denom);
+    }
+    if (hipMalloc(&h->d_PT, PT.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(h->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      sri_rod_destroy(h);
+      return SRI_ENOMEM;
+    }
   }
   *out = h;
+  return SRI_OK;
+}
+
+int sri_rod_set_predictor(sri_rod_t* h, int enable) {
+  if (h == nullptr) return SRI_EINVAL;
+  if (enable && h->coarse == nullptr) return SRI_EUNSUPPORTED;
+  h->use_predictor = enable != 0;
   return SRI_OK;
 }
 
@@ -303,6 +400,8 @@ int sri_rod_destroy(sri_rod_t* h) {
   sri::RodDeviceGuard guard;
   (void)guard.enter(h->device);
   if (h->resident) sri::resident_destroy(h->resident);
+  if (h->coarse) sri::resident_destroy(h->coarse);
+  if (h->d_PT) (void)hipFree(h->d_PT);
   if (h->integ) sri_apply_destroy(h->integ);
   double* bufs[] = {h->d_nodes, h->d_leg, h->d_K, h->d_G, h->d_Qa, h->d_B, h->d_xb4, h->d_xb3, h->d_tips};
   for (double* b : bufs)
@@ -406,8 +505,34 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   ROD_HIP(hipGetLastError());
   double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = m)
   double* nxt = h->d_Qa;
-  rc = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, cur, m, stream);
-  if (rc != SRI_OK) return rc;
+  // Start of the fixed point.  With the predictor (N > 64): solve the same rods on a 32-node grid with the on-chip
+  // pipeline (a fraction of one fine iteration), interpolate to the fine nodes, G^0 = 1/2 A(K) Q^0 — the fine loop then
+  // starts within ~tol of its fixed point and needs a couple of iterations instead of ~20.  The answer is still the
+  // fixed point of the FINE system, monitored and confirmed exactly as without the predictor; if the coarse solve
+  // fails (NaN), the plain start Q^0 = q_init is used.
+  bool predicted = false;
+  if (h->coarse != nullptr && h->use_predictor) {
+    constexpr uint32_t mc = sri::kCoarseN - 1;
+    double* dQc = h->d_B;                                      // free until the position step: m*3 >= mc*4 doubles per rod
+    uint32_t itc = 0;
+    double updc = 0.0;
+    const uint32_t coarse_iters = max_iter < 100 ? max_iter : 100;
+    int rcc = sri::resident_integrate(h->coarse, d_qe, rods, qi, nullptr, dQc, mc, nullptr, 0, 0.25 * tol, coarse_iters, &itc, &updc,
+                                      stream_);
+    if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
+      const dim3 grid(static_cast<unsigned>((rods + sri::kProlongRods - 1) / sri::kProlongRods), (m + 255) / 256);
+      hipLaunchKernelGGL(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
+                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, static_cast<size_t>(m), h->d_tips + cols);
+      ROD_HIP(hipGetLastError());
+      predicted = true;
+    } else if (rcc != SRI_OK && rcc != SRI_ENOTCONVERGED) {
+      return rcc;
+    }
+  }
+  if (!predicted) {
+    rc = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, cur, m, stream);
+    if (rc != SRI_OK) return rc;
+  }
 
   // Fixed-point loop, one fused launch per iteration:  G^{k+1} = 1/2 A(K) Q^{k+1},  Q^{k+1} = Dnn^-1 G^k - w q0^T.
   // DEVICE-DRIVEN: convergence is decided on the GPU.  Every fused step leaves the largest change of the TIP node of
@@ -428,10 +553,12 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   ROD_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
   ROD_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
   auto cleanup = [&]() { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); (void)hipHostFree(h_state); };
-  // tips of Q^0 (what iteration 0 compares with): q_init in every column
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
-                     qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
-  ROD_HIP(hipGetLastError());
+  // tips of Q^0 (what iteration 0 compares with): q_init in every column, or what the predictor left there
+  if (!predicted) {
+    hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                       qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
+    ROD_HIP(hipGetLastError());
+  }
   ROD_HIP(hipMemsetAsync(h->d_state, 0, 4 * sizeof(unsigned long long), stream));
   double tip_tol = tol;
   uint32_t enqueued = 0;                                        // iterations enqueued so far (k of the next one)

@@ -196,3 +196,33 @@ def test_nan_strain_is_reported_not_hidden(sri, n, resident):
     with pytest.raises(sri.SriError) as e:
         rod.integrate(qe, max_iter=40)
     assert e.value.status == -7 and rod.iterations == 40 and math.isnan(rod.last_update)
+
+
+@pytest.mark.parametrize("n,rods", [(80, 37), (129, 16), (200, 5)])
+def test_large_grid_predictor_matches_oracle_and_plain_start(sri, oracle, n, rods):
+    """N > 64: the fixed point started from the interpolated 32-node solution (default) and from Q = q_init must both
+    land on the oracle's dense solve; the predictor only shortens the iteration."""
+    import torch
+
+    qe = _qe_batch(rods, seed=n)
+    dqe = torch.from_numpy(qe).cuda()
+    q_init = np.array([0.8, 0.0, 0.6, 0.0])
+    r_init = np.array([0.5, -1.0, 2.0])
+    rod = sri.RodIntegrator(n)
+    Qp, Rp = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_pred = rod.iterations
+    rod.set_predictor(False)
+    Qn, Rn = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_plain = rod.iterations
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, n, qe, q_init, r_init)
+    for Q, R in ((Qp, Rp), (Qn, Rn)):
+        relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
+        relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
+        assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
+    assert (Qp - Qn).abs().max().item() <= 1e-13
+    assert it_pred <= 8 < it_plain, (it_pred, it_plain)
+    small = sri.RodIntegrator(32)
+    with pytest.raises(sri.SriError) as e:
+        small.set_predictor(True)
+    assert e.value.status == -6
