@@ -152,6 +152,49 @@ __global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_
   }
 }
 
+// Whole-panel confirmation of the fixed point in one pass: max over (rod, node, component) of |1/2 A(K) Q - G| with K
+// evaluated from qe on the fly (same arithmetic as strain_kernel + quat_rhs_kernel) -> *result as the bits of a
+// non-negative double (NaN -> largest).  Reads 8 doubles per rod and node, writes nothing.
+__global__ void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double* __restrict__ nodes, const double* __restrict__ qe,
+                                           const double* __restrict__ Q, size_t ldq, const double* __restrict__ G, size_t ldg,
+                                           unsigned long long* result) {
+  double local = 0.0;
+  const size_t total = rods * m;
+  for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t rod = t / m;
+    const uint32_t i = static_cast<uint32_t>(t % m);
+    const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+    const double P0 = 1.0, P1 = x;
+    const double P2 = ((2 * 1 + 1) * x * P1 - 1 * P0) / (1 + 1);
+    const double* q = qe + rod * 9;
+    double hk[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double s = P0 * q[a * 3 + 0];
+      s = s + P1 * q[a * 3 + 1];
+      s = s + P2 * q[a * 3 + 2];
+      hk[a] = 0.5 * s;
+    }
+    double gq[4];
+    quat_rhs_half(hk[0], hk[1], hk[2], Q[(rod * 4 + 0) * ldq + i], Q[(rod * 4 + 1) * ldq + i], Q[(rod * 4 + 2) * ldq + i],
+                  Q[(rod * 4 + 3) * ldq + i], gq);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double d = fabs(gq[a] - G[(rod * 4 + a) * ldg + i]);
+      local = d > local || d != d ? d : local;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double other = __shfl_xor(local, off);
+    local = (other > local || other != other) ? other : local;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long bits = (local != local) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(local));
+    atomicMax(result, bits);
+  }
+}
+
 // Coarse-to-fine start of the fixed point ("nested iteration"): the quaternions solved on a coarse Chebyshev grid
 // (Nc nodes, on-chip pipeline) are interpolated to the fine unknown nodes by the barycentric matrix P — the base node
 // X = 0 is a coarse node too and carries q0 — and turned into the first right-hand side G^0 = 1/2 A(K) Q^0.
@@ -497,11 +540,9 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   const uint32_t m = h->m;
   const size_t cols = 4 * rods;
 
-  rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, m, stream);
-  if (rc != SRI_OK) return rc;
-  // Q^0 = q_init at every node (in the caller's panel); xb = the base value of every column; G^0 = 1/2 A(K) Q^0
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
-                     qi[0], qi[1], qi[2], qi[3], dQ, ldq, h->d_xb4);
+  // xb = the base value of every column
+  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                     qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4);
   ROD_HIP(hipGetLastError());
   double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = m)
   double* nxt = h->d_Qa;
@@ -530,6 +571,12 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     }
   }
   if (!predicted) {
+    // Q^0 = q_init at every node (in the caller's panel), G^0 = 1/2 A(K) Q^0
+    rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, m, stream);
+    if (rc != SRI_OK) return rc;
+    hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
+                       qi[0], qi[1], qi[2], qi[3], dQ, ldq, static_cast<double*>(nullptr));
+    ROD_HIP(hipGetLastError());
     rc = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, cur, m, stream);
     if (rc != SRI_OK) return rc;
   }
@@ -589,10 +636,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     nxt = bufs[(it + 1) & 1];
     int r = sri_integrate(h->integ, cur, m, h->d_xb4, dQ, ldq, cols, stream);
     if (r != SRI_OK) return r;
-    r = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, nxt, m, stream);
-    if (r != SRI_OK) return r;
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(sri::max_abs_diff_kernel, dim3(1024), dim3(256), 0, stream, m, cols, nxt, static_cast<size_t>(m), cur,
+    hipLaunchKernelGGL(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
                        static_cast<size_t>(m), h->d_diff);
     ROD_HIP(hipGetLastError());
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -645,8 +690,8 @@ int sri_rod_integrate_positions(sri_rod_t* h, const double* dQ, size_t ldq, size
   const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
   const double* ri = r_init ? r_init : r0;
   const size_t cols = 3 * rods;
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 3u,
-                     ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(m), h->d_xb3);
+  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 3u,
+                     ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
   ROD_HIP(hipGetLastError());
   rc = sri_rod_position_rhs(h, dQ, ldq, rods, h->d_B, m, stream);
   if (rc != SRI_OK) return rc;
