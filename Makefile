@@ -12,10 +12,13 @@ oracle:
 	$(MAKE) -C oracle
 
 # measurement tooling (not product code); binaries land in build/ (git-ignored, travels with gpurun)
-tools: build/mfma_f64_probe build/apply_diag
+tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe
 
 build/mfma_f64_probe: tools/mfma_f64_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -include algorithm $< -o $@
+
+build/store_rate_probe: tools/store_rate_probe.hip
+	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
 build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Wno-pass-failed tools/apply_diag.hip $(PKG)/csrc/sri_host.cpp -o $@

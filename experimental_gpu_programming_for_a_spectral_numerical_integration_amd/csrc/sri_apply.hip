@@ -178,7 +178,8 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
 //           4 = no Y stores, 8 = read LDS fragments only in the first stage,
 //           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts,
-//           32 = the early wave group stores nothing, 64 = the late wave group stores nothing.
+//           32 = the early wave group stores nothing, 64 = the late wave group stores nothing,
+//           128 = all tiles store over the first column tile (store issue without HBM write traffic).
 //   EPI   : EPI_QUAT fuses the caller on the far side of the product into the store stage:
 //           the panel is 4 columns (w, x, y, z) per rod, Q = A X - w xb^T is the new quaternion iterate, and what
 //           is stored is the NEXT right-hand side G = 1/2 A(K) Q of main.cpp:71-84 with K = Phi(X_row) qe
@@ -556,7 +557,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
     const uint32_t rb_c = tile / p.col_tiles;
-    const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
+    // ABL & 128: every tile stores over the FIRST column tile (same instructions, no HBM write traffic)
+    const size_t col0_c = (ABL & 128) ? 0 : static_cast<size_t>(tile % p.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
     const size_t col_base = col0_c + wn * (TN * 16) + g;
     // "full": every column of the tile exists and at most the very last row of the row block is missing

@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
   ablate<5>("no A, no Y (X fetch only)", a, col_tiles, blocks, flops, dS);
   ablate<32>("early group stores nothing", a, col_tiles, blocks, flops, dS);
   ablate<64>("late group stores nothing", a, col_tiles, blocks, flops, dS);
+  ablate<128>("stores alias one tile (no HBM writes)", a, col_tiles, blocks, flops, dS);
   ablate<16>("staggered start (b%8)/8 tile", a, col_tiles, blocks, flops, dS);
   ablate<0>("none again", a, col_tiles, blocks, flops, dS);
   ablate<16>("staggered start again", a, col_tiles, blocks, flops, dS);
