@@ -226,3 +226,21 @@ def test_large_grid_predictor_matches_oracle_and_plain_start(sri, oracle, n, rod
     with pytest.raises(sri.SriError) as e:
         small.set_predictor(True)
     assert e.value.status == -6
+
+
+@pytest.mark.parametrize("n,rods", [(17, 9), (33, 21), (65, 6), (97, 4)])
+def test_grids_without_a_free_k_slot(sri, oracle, n, rods):
+    """(N-1) % 16 == 0: no free slot in the last k chunk, so the initial-value term is an epilogue, the on-chip pipeline
+    does not apply and (N = 65, 97) the predictor feeds a streaming loop whose operator has no tail."""
+    import torch
+
+    qe = _qe_batch(rods, seed=100 + n)
+    rod = sri.RodIntegrator(n)
+    q_init = np.array([0.6, 0.0, 0.0, 0.8])
+    r_init = np.array([-1.0, 0.25, 3.0])
+    Q, R = rod.integrate(torch.from_numpy(qe).cuda(), q_init=q_init, r_init=r_init)
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, n, qe, q_init, r_init)
+    relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
+    relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
+    assert relq <= 1e-12 and relr <= 1e-12, (relq, relr, rod.iterations)
