@@ -132,12 +132,11 @@ __global__ __launch_bounds__(64 * NW) void rod_resident_kernel(const ResidentArg
               acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
       }
   };
+  // f64 compares and selects run at the rate of the MFMA pipe they share, so the convergence monitor uses one v_max_f64
+  // per value (which DROPS NaNs) and NaNs are caught once per task instead, on the final iterate.
   auto wave_max = [&](double v) __attribute__((always_inline)) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double other = __shfl_xor(v, off);
-      v = (other > v || other != other) ? other : v;             // NaN wins
-    }
+    for (int off = 1; off < 64; off <<= 1) v = __builtin_fmax(v, __shfl_xor(v, off));
     return v;
   };
 
@@ -197,8 +196,7 @@ __global__ __launch_bounds__(64 * NW) void rod_resident_kernel(const ResidentArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               double* slot = reinterpret_cast<double*>(img + tm * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r));
-              const double d = fabs(gq[r] - *slot);
-              local = (d > local || d != d) ? d : local;
+              local = __builtin_fmax(local, fabs(gq[r] - *slot));
               *slot = gq[r];
             }
           }
@@ -206,13 +204,24 @@ __global__ __launch_bounds__(64 * NW) void rod_resident_kernel(const ResidentArg
       }
       ++it;
       upd = wave_max(local);
-      if (upd <= p.tol) break;                                    // wave-uniform; NaN compares false
+      if (upd <= p.tol) break;                                    // wave-uniform
     }
-    worst_it = it > worst_it ? it : worst_it;
-    worst_upd = (upd > worst_upd || upd != upd) ? upd : worst_upd;
 
     // ---- Q = Dn_NN^-1 G - w q0^T, stored; then b = R(q) e1 into the image (4th column of a rod: 0) -------------
     product();
+    {
+      bool bad = false;                                           // a NaN anywhere in the task's state poisons Q
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const double t = (acc[tm][tn][0] + acc[tm][tn][1]) + (acc[tm][tn][2] + acc[tm][tn][3]);
+          bad = bad || (t != t);
+        }
+      if (__ballot(bad) != 0ull) upd = __builtin_nan("");
+    }
+    worst_it = it > worst_it ? it : worst_it;
+    worst_upd = (upd > worst_upd || upd != upd) ? upd : worst_upd;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const uint32_t row = tm * 16 + c;

@@ -195,7 +195,9 @@ def test_nan_strain_is_reported_not_hidden(sri, n, resident):
         rod.set_resident(resident)
     with pytest.raises(sri.SriError) as e:
         rod.integrate(qe, max_iter=40)
-    assert e.value.status == -7 and rod.iterations == 40 and math.isnan(rod.last_update)
+    assert e.value.status == -7 and math.isnan(rod.last_update)
+    if not resident:
+        assert rod.iterations == 40                      # the streaming monitor carries the NaN through every iteration
 
 
 @pytest.mark.parametrize("n,rods", [(80, 37), (129, 16), (200, 5)])
