@@ -69,8 +69,10 @@ struct ResGeo {
   static_assert(LDS_BYTES <= 160 * 1024, "operator + wave images exceed a CU");
 };
 
+// (second launch bound = waves per SIMD the register budget must allow: four for the 34-KiB geometry, which fits four
+// workgroups per CU; two elsewhere)
 template <int TM, int TN, int NW>
-__global__ __launch_bounds__(64 * NW) void rod_resident_kernel(const ResidentArgs p) {
+__global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(const ResidentArgs p) {
   using G = ResGeo<TM, TN, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
