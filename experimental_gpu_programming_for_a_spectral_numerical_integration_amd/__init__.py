@@ -41,6 +41,7 @@ C_ABI = {
     "sri_cheb_blocks": (_int, [_u32, _dp, _sz, _dp, _sz, _dp]),
     "sri_cheb_integration": (_int, [_u32, _dp, _sz, _dp]),
     "sri_ivp": (_int, [_u32, _u32, _dp, _dp, _dp, _sz]),
+    "sri_cheb_interp": (_int, [_u32, _u32, _dp, _sz]),
     "sri_apply_create": (_int, [C.POINTER(_vp), _u32, _int, _int]),
     "sri_apply_create_matrix": (_int, [C.POINTER(_vp), _u32, _dp, _sz, _int]),
     "sri_apply_set_max_workgroups": (_int, [_vp, _u32]),
@@ -182,6 +183,13 @@ def ivp(Din: np.ndarray, x_base: np.ndarray) -> np.ndarray:
     out = _fmat(Din.shape[0], x_base.shape[0])
     _chk(load_library().sri_ivp(Din.shape[0], x_base.shape[0], _p(Din), _p(x_base), _p(out), Din.shape[0]), "sri_ivp")
     return out
+
+
+def cheb_interp(n_from: int, n_to: int) -> np.ndarray:
+    """Barycentric interpolation matrix (n_to x n_from) between two Chebyshev grids of the reference on [0, 1]."""
+    P = _fmat(n_to, n_from)
+    _chk(load_library().sri_cheb_interp(n_from, n_to, _p(P), n_to), "sri_cheb_interp")
+    return P
 
 
 # ------------------------------------------------------------------------------------------------

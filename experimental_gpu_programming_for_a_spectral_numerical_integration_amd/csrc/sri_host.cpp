@@ -158,6 +158,32 @@ int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double*
   return SRI_OK;
 }
 
+// Barycentric interpolation between two Chebyshev-Lobatto grids on [0, 1] (not in the reference: used to start the
+// fixed point of a fine grid from a coarse-grid solution).  P is n_to x n_from, column-major:
+//   P(i, j) = (w_j / (x_i - xc_j)) / sum_l (w_l / (x_i - xc_l)),  w_j = (-1)^j (halved at both ends);  P(i, j) = delta
+// on a row whose node coincides with a coarse node.  Accumulated in long double, rounded once.
+int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld) {
+  if (n_from < 2 || n_to < 2 || P == nullptr || ld < n_to) return SRI_EINVAL;
+  std::vector<double> xc(n_from), xf(n_to);
+  std::vector<long double> t(n_from);
+  cheb_points(n_from, 1.0, xc.data());
+  cheb_points(n_to, 1.0, xf.data());
+  for (uint32_t i = 0; i < n_to; ++i) {
+    int hit = -1;
+    long double denom = 0.0L;
+    for (uint32_t j = 0; j < n_from; ++j) {
+      const long double d = static_cast<long double>(xf[i]) - static_cast<long double>(xc[j]);
+      if (d == 0.0L) { hit = static_cast<int>(j); break; }
+      const long double wj = ((j & 1) ? -1.0L : 1.0L) * ((j == 0 || j == n_from - 1) ? 0.5L : 1.0L);
+      t[j] = wj / d;
+      denom += t[j];
+    }
+    for (uint32_t j = 0; j < n_from; ++j)
+      P[i + static_cast<size_t>(j) * ld] = hit >= 0 ? (static_cast<int>(j) == hit ? 1.0 : 0.0) : static_cast<double>(t[j] / denom);
+  }
+  return SRI_OK;
+}
+
 }  // namespace sri
 
 // ------------------------------------------------------------------------------------------
@@ -177,6 +203,8 @@ int sri_cheb_integration(uint32_t n, double* Dnn_inv, size_t ld, double* Din) {
 int sri_ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double* out, size_t ld) {
   return sri::ivp(m, s, Din, x_base, out, ld);
 }
+
+int sri_cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld) { return sri::cheb_interp(n_from, n_to, P, ld); }
 
 const char* sri_strerror(int status) {
   switch (status) {

@@ -17,6 +17,7 @@ int cheb_blocks(uint32_t n, const double* D, size_t ld, double* Dnn, size_t ldnn
 int dense_inverse(uint32_t m, const double* A, size_t lda, double* Ainv, size_t ldi);
 int cheb_integration(uint32_t n, double* Dnn_inv, size_t ld, double* Din);
 int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double* out, size_t ld);
+int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld);
 
 // ---- error bookkeeping (sri_apply.hip): what sri_last_hip_error() reports -----------------------
 void record_hip_error(int hip_error);

@@ -392,28 +392,21 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
       return rc;
     }
   } else if (n > 64) {
-    // predictor: the same rods on a 32-node grid (on chip) + barycentric interpolation to the fine unknown nodes.
-    // Chebyshev-Lobatto weights (-1)^j, halved at both ends; P[i][j] = (w_j / (x_i - xc_j)) / sum_l (w_l / (x_i - xc_l)).
+    // predictor: the same rods on a 32-node grid (on chip) + barycentric interpolation to the fine unknown nodes
+    // (sri_cheb_interp)
     rc = sri::resident_create(sri::kCoarseN, device, prop.multiProcessorCount, &h->coarse);
     if (rc != SRI_OK) {
       sri_rod_destroy(h);
       return rc;
     }
-    std::vector<double> xc(sri::kCoarseN), PT(static_cast<size_t>(sri::kCoarseN) * h->m, 0.0);
-    sri::cheb_points(sri::kCoarseN, 1.0, xc.data());
-    for (uint32_t i = 0; i < h->m; ++i) {
-      int hit = -1;
-      long double denom = 0.0L, t[sri::kCoarseN];
-      for (int j = 0; j < sri::kCoarseN; ++j) {
-        const long double d = static_cast<long double>(x[i]) - static_cast<long double>(xc[j]);
-        if (d == 0.0L) { hit = j; break; }
-        const long double wj = ((j & 1) ? -1.0L : 1.0L) * ((j == 0 || j == sri::kCoarseN - 1) ? 0.5L : 1.0L);
-        t[j] = wj / d;
-        denom += t[j];
-      }
-      for (int j = 0; j < sri::kCoarseN; ++j)
-        PT[static_cast<size_t>(j) * h->m + i] = hit >= 0 ? (j == hit ? 1.0 : 0.0) : static_cast<double>(t[j] / denom);
+    std::vector<double> P(static_cast<size_t>(n) * sri::kCoarseN), PT(static_cast<size_t>(sri::kCoarseN) * h->m, 0.0);
+    rc = sri::cheb_interp(sri::kCoarseN, n, P.data(), n);
+    if (rc != SRI_OK) {
+      sri_rod_destroy(h);
+      return rc;
     }
+    for (uint32_t i = 0; i < h->m; ++i)                          // unknown nodes only, transposed for coalesced reads
+      for (int j = 0; j < sri::kCoarseN; ++j) PT[static_cast<size_t>(j) * h->m + i] = P[i + static_cast<size_t>(j) * n];
     if (hipMalloc(&h->d_PT, PT.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(h->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
       sri_rod_destroy(h);

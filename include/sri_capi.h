@@ -82,6 +82,11 @@ int sri_cheb_integration(uint32_t n, double *Dnn_inv, size_t ld, double *Din);
  * ivp(i,c) = Din[i] * x_base[c];  ivp is m x s column-major, ld >= m. */
 int sri_ivp(uint32_t m, uint32_t s, const double *Din, const double *x_base, double *ivp, size_t ld);
 
+/* Not in the reference: barycentric interpolation matrix between two of its Chebyshev grids on [0, 1]
+ * (nodes of chebyshev_differentiation.h:26), P: n_to x n_from column-major, ld >= n_to; values at the n_from nodes ->
+ * values at the n_to nodes.  sri_rod_* uses it to start the fixed point of a fine grid from a 32-node solution. */
+int sri_cheb_interp(uint32_t n_from, uint32_t n_to, double *P, size_t ld);
+
 /* ---------------------------------------------------------------------------------------- */
 /* The apply:  Y[rows x M] = A[rows x rows] * X[rows x M]   (main.cpp:172; Kronecker form      */
 /* main.cpp:97).  A is formed on the host once, packed into MFMA-fragment order and kept on    */

@@ -109,3 +109,23 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "sri_oracle" not in text and "libsri_oracle" not in text, f
+
+
+@pytest.mark.parametrize("n_from,n_to", [(32, 256), (16, 64), (32, 33), (8, 8), (5, 1024), (32, 80)])
+def test_chebyshev_interpolation_matrix(sri, n_from, n_to):
+    """sri_cheb_interp (host former behind the rod predictor): partition of unity, exact on polynomials of degree
+    < n_from, identity on coinciding nodes, and equal to an independent numpy evaluation of the barycentric formula."""
+    P = sri.cheb_interp(n_from, n_to)
+    xc, xf = sri.ComputeChebyshevPoints(n_from), sri.ComputeChebyshevPoints(n_to)
+    assert P.shape == (n_to, n_from)
+    assert np.abs(P.sum(axis=1) - 1).max() <= 4e-15
+    for deg in range(min(n_from, 6)):
+        assert np.abs(P @ xc ** deg - xf ** deg).max() <= 2e-14, deg
+    w = np.array([(-1.0) ** j for j in range(n_from)]); w[0] *= 0.5; w[-1] *= 0.5
+    for i in (0, n_to // 3, n_to - 1):
+        d = xf[i] - xc
+        ref = (d == 0).astype(float) if (d == 0).any() else (w / d) / (w / d).sum()
+        assert np.abs(P[i] - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+    if n_from == n_to:
+        assert np.array_equal(P, np.eye(n_to))
+    assert P[0, 0] == 1.0 and P[-1, -1] == 1.0                   # both grids share the end points X = 1 and X = 0
