@@ -246,3 +246,20 @@ def test_grids_without_a_free_k_slot(sri, oracle, n, rods):
     relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
     relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
     assert relq <= 1e-12 and relr <= 1e-12, (relq, relr, rod.iterations)
+
+
+@pytest.mark.parametrize("n,scale", [(16, 6.0), (64, 8.0), (129, 8.0)])
+def test_strongly_curved_rods(sri, oracle, n, scale):
+    """|K| up to ~ 3 * scale * sqrt(3): many more Picard sweeps (the contraction is (|K|/2)^k / k!), a coarse grid that
+    resolves less, larger rounding noise — the answer must still be the oracle's."""
+    import torch
+
+    rods = 6
+    qe = _qe_batch(rods, seed=77, scale=scale)
+    rod = sri.RodIntegrator(n)
+    Q, R = rod.integrate(torch.from_numpy(qe).cuda(), tol=1e-13, max_iter=400)
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, n, qe)
+    relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
+    relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
+    assert relq <= 2e-12 and relr <= 2e-12, (relq, relr, rod.iterations, rod.last_update)
