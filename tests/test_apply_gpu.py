@@ -359,3 +359,29 @@ def test_differentiate_then_integrate_roundtrip(sri, oracle):
     rel = (W - V).norm() / V.norm()
     # cond_2(Dn_NN) = 5.2e4 at N=256 bounds the amplification of rounding
     assert rel.item() <= 5.2e4 * 2.0 ** -53 * 64, rel.item()
+
+
+def test_randomised_shape_sweep_against_the_oracle_product(sri, oracle):
+    """Seeded sweep over shapes no fixed list would contain: random operator sizes 2..300 (all three geometries, the
+    register path, tails), random column counts, random leading dimensions on both panels, arbitrary dense operators
+    (sri_apply_create_matrix) — against the oracle's product of the same matrix (sequential-k dot products)."""
+    import torch
+
+    rng = np.random.default_rng(20261003)
+    for case in range(40):
+        rows = int(rng.choice([rng.integers(2, 17), rng.integers(17, 65), rng.integers(65, 129), rng.integers(129, 301)]))
+        M = int(rng.integers(1, 700))
+        ldx, ldy = rows + int(rng.integers(0, 5)), rows + int(rng.integers(0, 5))
+        A = np.asfortranarray(rng.uniform(-1, 1, size=(rows, rows)))
+        op = sri.SpectralApply(rows, matrix=A)
+        Xp = torch.from_numpy(rng.uniform(-1, 1, size=(M, ldx))).cuda()
+        Yp = torch.full((M, ldy), float("nan"), dtype=torch.float64, device="cuda")
+        rc = sri.load_library().sri_apply(op._h, Xp.data_ptr(), ldx, Yp.data_ptr(), ldy, M,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, (case, rows, M, ldx, ldy)
+        torch.cuda.synchronize()
+        Y = Yp[:, :rows].cpu().numpy()
+        ref = oracle.apply(A, np.asfortranarray(Xp[:, :rows].cpu().numpy().T)).T
+        rel = np.linalg.norm(Y - ref) / np.linalg.norm(ref)
+        assert rel <= 1e-12, (case, rows, M, ldx, ldy, rel)
+        assert torch.isnan(Yp[:, rows:]).all()                    # the padding between columns is never written
