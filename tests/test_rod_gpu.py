@@ -287,3 +287,24 @@ def test_fused_step_randomised_sweep(sri):
         torch.cuda.synchronize()
         assert torch.equal(Gn, ref), (case, n, rods)
         assert torch.equal(tips, Q[:, :, 0]), (case, n, rods)
+
+
+def test_rod_pipeline_randomised_sweep(sri, oracle):
+    """14 seeded random grids N in 4..110 with a few rods each, default launch policy (on-chip pipeline, streaming loop,
+    predictor — whatever the handle picks): quaternions and positions against the oracle's dense solve."""
+    import torch
+
+    rng = np.random.default_rng(777)
+    for case in range(14):
+        n = int(rng.choice([rng.integers(4, 18), rng.integers(18, 50), rng.integers(50, 66), rng.integers(66, 111)]))
+        rods = int(rng.integers(1, 24))
+        qe = rng.uniform(-2, 2, size=(rods, 9))
+        q_init = rng.normal(size=4); q_init /= np.linalg.norm(q_init)
+        r_init = rng.normal(size=3)
+        rod = sri.RodIntegrator(n)
+        Q, R = rod.integrate(torch.from_numpy(qe).cuda(), q_init=q_init, r_init=r_init)
+        torch.cuda.synchronize()
+        Qo, Ro = _oracle_rods(oracle, n, qe, q_init, r_init)
+        relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
+        relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
+        assert relq <= 1e-12 and relr <= 1e-12, (case, n, rods, relq, relr, rod.iterations)
