@@ -289,6 +289,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "columns_per_s": value * 4,             # the s = 3 position case is this / 3 rod-states/s
             "parity_fro_rel_err_sampled": verify,
         }
         if full_gather_ms is not None:
