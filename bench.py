@@ -283,8 +283,13 @@ def main():
                        "kernel": op.last_kernel, "gather": args.gather if use_dist else "none",
                        "clock_ramp_ms_untimed": args.ramp_ms,
                        "cus_reserved_for_collective": reserve},
-            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+            # AI = N/8 flop/B against the machine balance 78.6 TF / 8 TB/s = 9.8 flop/B: HBM-bound below N ~ 79
+            "roofline": ({"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                          "frac": achieved_tf / PEAK_FP64_MFMA_TFLOPS}
+                         if n / 8.0 >= PEAK_FP64_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS else
+                         {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}) |
+                        {"traffic": traffic, "achieved_TFLOPs": achieved_tf,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
