@@ -155,9 +155,11 @@ __global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_
 // Whole-panel confirmation of the fixed point in one pass: max over (rod, node, component) of |1/2 A(K) Q - G| with K
 // evaluated from qe on the fly (same arithmetic as strain_kernel + quat_rhs_kernel) -> *result as the bits of a
 // non-negative double (NaN -> largest).  Reads 8 doubles per rod and node, writes nothing.
+// Optionally also emits the position right-hand side b = R(q) e1 of every node (B != nullptr; same arithmetic as
+// position_rhs_kernel), since Q is in registers anyway.
 __global__ void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double* __restrict__ nodes, const double* __restrict__ qe,
                                            const double* __restrict__ Q, size_t ldq, const double* __restrict__ G, size_t ldg,
-                                           unsigned long long* result) {
+                                           unsigned long long* result, double* __restrict__ B, size_t ldb) {
   double local = 0.0;
   const size_t total = rods * m;
   for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
@@ -176,9 +178,17 @@ __global__ void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double
       s = s + P2 * q[a * 3 + 2];
       hk[a] = 0.5 * s;
     }
+    const double w = Q[(rod * 4 + 0) * ldq + i], x4 = Q[(rod * 4 + 1) * ldq + i];
+    const double y = Q[(rod * 4 + 2) * ldq + i], z = Q[(rod * 4 + 3) * ldq + i];
     double gq[4];
-    quat_rhs_half(hk[0], hk[1], hk[2], Q[(rod * 4 + 0) * ldq + i], Q[(rod * 4 + 1) * ldq + i], Q[(rod * 4 + 2) * ldq + i],
-                  Q[(rod * 4 + 3) * ldq + i], gq);
+    quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
+    if (B != nullptr) {
+      const double ty = 2 * y, tz = 2 * z;
+      const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
+      B[(rod * 3 + 0) * ldb + i] = 1 - (tyy + tzz);
+      B[(rod * 3 + 1) * ldb + i] = txy + twz;
+      B[(rod * 3 + 2) * ldb + i] = txz - twy;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const double d = fabs(gq[a] - G[(rod * 4 + a) * ldg + i]);
@@ -303,6 +313,7 @@ struct sri_rod_handle {
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
   sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64, (N-1) % 16 != 0), else null
   bool use_resident = true;
+  bool emit_position_rhs = false;         // set by sri_rod_integrate: the confirmation pass also writes b = R(q) e1 into d_B
   sri::ResidentRod* coarse = nullptr;     // N > 64: on-chip solver on a 32-node grid, predictor of the fine fixed point
   double* d_PT = nullptr;                 // its barycentric interpolation matrix to the fine unknown nodes, transposed
   bool use_predictor = true;
@@ -634,7 +645,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     if (r != SRI_OK) return r;
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
-                       static_cast<size_t>(m), h->d_diff);
+                       static_cast<size_t>(m), h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr),
+                       static_cast<size_t>(m));
     ROD_HIP(hipGetLastError());
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipStreamSynchronize(stream));
@@ -711,9 +723,23 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
     return sri::resident_integrate(h->resident, d_qe, rods, q_init ? q_init : qi_default, r_init, dQ, ldq, dR, ldr, tol, max_iter,
                                    iters_out, last_update_out, stream);
   }
+  if (h == nullptr || (rods > 0 && dR == nullptr) || ldr < h->m) return SRI_EINVAL;
+  // streaming path: the confirmation pass of the quaternion loop has Q in registers and leaves b = R(q) e1 in the
+  // workspace, so the position step is just the hot product
+  h->emit_position_rhs = true;
   int rc = sri_rod_integrate_quaternions(h, d_qe, rods, q_init, dQ, ldq, tol, max_iter, iters_out, last_update_out, stream);
+  h->emit_position_rhs = false;
+  if (rc != SRI_OK || rods == 0) return rc;
+  sri::RodDeviceGuard guard;
+  rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  return sri_rod_integrate_positions(h, dQ, ldq, rods, r_init, dR, ldr, stream);
+  const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
+  const double* ri = r_init ? r_init : r0;
+  const size_t cols = 3 * rods;
+  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
+                     cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
+  ROD_HIP(hipGetLastError());
+  return sri_integrate(h->integ, h->d_B, h->m, h->d_xb3, dR, ldr, cols, stream);            // main.cpp:172
 }
 
 }  // extern "C"
