@@ -38,6 +38,10 @@
 //   * Any fp64 panel qualifies: 8-byte alignment is enough for LDS-DMA and 16-byte stores
 //     (tools/unaligned_probe.hip); rows % 16 != 0 (every integration operator: N-1 rows) is handled by
 //     safe source addresses + an LDS fix-up of the last k chunk (template parameter TAIL).
+//   * The initial-value term of sri_integrate (Y -= w x_base^T, main.cpp:162-164) costs nothing when rows % 16 != 0:
+//     -w is packed as operator column k = rows, x_base rides in the matching slot of the X image (FOLD).
+//   * EPI_QUAT turns the store stage into the caller on the far side of the product: the next right-hand side
+//     1/2 A(K) Q of the quaternion fixed point is formed from the accumulators (sri_rod.hip drives it).
 //
 // There is no CPU fallback: without a gfx950 device every entry point fails with an error.
 #include <hip/hip_runtime.h>
