@@ -73,8 +73,8 @@ static void run(const char* name, int waves, int blocks) {
   std::vector<unsigned long long> is, dn;
   for (size_t i = 0; i < h.size(); i += 2) { is.push_back(h[i]); dn.push_back(h[i + 1]); }
   std::sort(is.begin(), is.end()); std::sort(dn.begin(), dn.end());
-  // s_memtime ticks at 100 MHz on gfx950; report in shader cycles at ~2.4 GHz as ticks*24 for orientation
-  printf("%-34s waves/CU %d blocks %4d : issue of 32 KiB/wave median %5llu ticks (p90 %5llu) ; until complete median %5llu ticks (p90 %5llu)   [1 tick = 10 ns]\n",
+  // s_memtime counts shader-clock cycles
+  printf("%-34s waves/CU %d blocks %4d : issue of 32 KiB/wave median %5llu cycles (p90 %5llu) ; until complete median %5llu cycles (p90 %5llu)\n",
          name, waves, blocks, is[is.size() / 2], is[is.size() * 9 / 10], dn[dn.size() / 2], dn[dn.size() * 9 / 10]);
   CK(hipFree(y)); CK(hipFree(o));
 }
