@@ -308,3 +308,43 @@ def test_rod_pipeline_randomised_sweep(sri, oracle):
         relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
         relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
         assert relq <= 1e-12 and relr <= 1e-12, (case, n, rods, relq, relr, rod.iterations)
+
+
+def test_fused_steps_in_a_hip_graph(sri):
+    """Four Picard iterations (fused step + in-launch tip monitor, ping-pong panels) captured once as a HIP graph and
+    replayed: the launch-bound inner loop as one graph launch.  Replays must reproduce the eager sequence bit for bit."""
+    import ctypes as C
+    import torch
+
+    n, rods, m = 128, 777, 127
+    lib = sri.load_library()
+    rod = sri.RodIntegrator(n)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qe = torch.rand((rods, 9), dtype=torch.float64, device="cuda", generator=g) * 4 - 2
+    q0 = torch.zeros((rods, 4), dtype=torch.float64, device="cuda"); q0[:, 0] = 1
+    G0 = torch.rand((rods, 4, m), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    bufs = [G0.clone(), torch.empty_like(G0)]
+    tips = [torch.zeros((rods, 4), dtype=torch.float64, device="cuda") for _ in range(2)]
+    upd = torch.zeros((1,), dtype=torch.int64, device="cuda")
+
+    def four_steps(stream):
+        for k in range(4):
+            rc = lib.sri_rod_quaternion_step(rod._h, qe.data_ptr(), bufs[k & 1].data_ptr(), m, q0.data_ptr(), rods,
+                                             bufs[(k + 1) & 1].data_ptr(), m, tips[k & 1].data_ptr(), tips[(k + 1) & 1].data_ptr(),
+                                             upd.data_ptr(), stream)
+            assert rc == 0
+
+    four_steps(torch.cuda.current_stream().cuda_stream)          # eager: result lands back in bufs[0]
+    torch.cuda.synchronize()
+    ref, ref_tips, ref_upd = bufs[0].clone(), tips[1].clone(), upd.clone()
+    bufs[0].copy_(G0); upd.zero_(); tips[0].zero_(); tips[1].zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            four_steps(side.cuda_stream)
+    bufs[0].copy_(G0); upd.zero_(); tips[0].zero_(); tips[1].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[0], ref) and torch.equal(tips[1], ref_tips) and torch.equal(upd, ref_upd)
