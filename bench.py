@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — the reference's headline metric on MI355X: rod-states/s of the fp64 D_N.X apply.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]           (N = 1)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--data {rod,uniform}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W  (N > 1, one rank per GPU, RCCL)
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the second command itself as a
+CHILD process (before anything here touches the GPU; never an exec), relays rank 0's JSON line and exits
+with the child's return code.
+
 A "step" is one pass of the hot path over one batch of synthetic state panels already resident in
 HBM: Y = D_N . X with N = 256 nodes and 65 536 rods (x 4 state columns) PER GPU — BASELINE.json
-configs[2] at N=1, configs[3] at 8 GPUs (weak scaling on the batch axis).  The apply needs no
-collective (rods are independent, the operator is replicated).  For N > 1 the job ends with ONE RCCL
-all-gather over xGMI of the integrated tip state of every rod (north_star: "all-gather ... only to
-reassemble the final integrated state"), inside the timed region; every apply emits its tip state from
-the kernel epilogue at no extra traffic.  `--gather tip` gathers after every step instead (overlapped on
-a side stream); the cost of one tip gather and of one full-panel gather are reported separately.
+configs[2] at N=1, configs[3] at 8 GPUs (weak scaling on the batch axis).  `--config` selects the
+other BASELINE configurations (2: N=64 / 4 096 rods, 5: N=1024 / 8 192 rods).  The panels are the
+synthetic rod-strain fields north_star names (`--data rod`, SURVEY §8d (ii): per rod qe ~ U[-2,2)^9,
+K = Phi(X) qe at the Chebyshev nodes, 4th column cos|K|) or U[-1,1) noise (`--data uniform`).
+The apply needs no collective (rods are independent, the operator is replicated).  For N > 1 the job
+ends with ONE RCCL all-gather over xGMI of the integrated tip state of every rod (north_star:
+"all-gather ... only to reassemble the final integrated state"), inside the timed region; every apply
+emits its tip state from the kernel epilogue at no extra traffic.  `--gather tip` gathers after every
+step instead (on a side stream); the cost of one tip gather and of one full-panel gather are reported
+separately.
 
 Rank 0 prints ONE JSON line.  `roofline` is computed from ALGORITHMIC flops (8 N^2 per rod-state,
 SURVEY.md §8d) and the kernel's mean launch duration measured here with HIP events on the launch
@@ -24,11 +32,12 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -37,8 +46,11 @@ if ROOT not in sys.path:
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet dense fp64 matrix peak; 77.5 measured (profiles/r01_mfma_f64_probe.log)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
+# BASELINE.json configs (index = position in its "configs" list + 1): (N, rods per GPU)
+CONFIGS = {2: (64, 4096), 3: (256, 65536), 4: (256, 65536), 5: (1024, 8192)}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -46,60 +58,163 @@ def parse():
     ap.add_argument("--ramp-ms", type=float, default=1500.0,
                     help="untimed clock ramp before the W warmup steps: an idle MI355X sits at ~160 MHz sclk and needs "
                          "several hundred ms of load to reach its sustained 2.37 GHz (profiles/r01_power_clock.log)")
-    ap.add_argument("--n", type=int, default=256, help="Chebyshev nodes N")
-    ap.add_argument("--rods", type=int, default=65536, help="rods per GPU (4 state columns each)")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configuration: 2 = N=64/4096 rods, 3 = N=256/65536 rods (default), "
+                         "4 = config 3 per GPU (pass --gpus 8), 5 = N=1024/8192 rods; --n/--rods override")
+    ap.add_argument("--n", type=int, default=None, help="Chebyshev nodes N (default 256)")
+    ap.add_argument("--rods", type=int, default=None, help="rods per GPU, 4 state columns each (default 65536)")
+    ap.add_argument("--data", choices=["rod", "uniform"], default="rod",
+                    help="rod = synthetic rod-strain fields (what north_star names), uniform = U[-1,1)")
     ap.add_argument("--operator", choices=["dn", "dnn_inv"], default="dn")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="number of distinct (X, Y) panel pairs the steps cycle through; config 2's 16.8 MB working "
+                         "set is Infinity-Cache resident when timed back to back (SURVEY H5): --rotate 32 streams "
+                         "it from HBM instead")
     ap.add_argument("--gather", choices=["final", "tip", "full", "none"], default="final",
                     help="exchange when N > 1: final = ONE all-gather of the integrated tip state after the K steps, "
-                         "inside the timed region (default); tip = one per step, overlapped on a side stream; "
+                         "inside the timed region (default); tip = one per step, on a side stream; "
                          "full = whole output panel per step; none")
+    ap.add_argument("--collective", choices=["capi", "torch"], default="capi",
+                    help="who issues the RCCL all-gather: capi = libsri_hip.so's sri_allgather_* (default), "
+                         "torch = torch.distributed")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="CUs left free for an overlapped RCCL kernel (0 = none: with 8 tiles per workgroup a smaller "
                          "grid costs a whole extra round of tiles, measured +12%%)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-verify", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    n0, r0 = CONFIGS[args.config if args.config is not None else 3]
+    args.n = n0 if args.n is None else args.n
+    args.rods = r0 if args.rods is None else args.rods
+    return args
 
 
-def cpu_baseline(n: int, budget_s: float):
-    """Oracle (kind "port") on a bounded sample, single thread like the reference's main.cpp."""
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n_gpus: int, argv, script: str = None) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start one rank per GPU as a CHILD
+    torch.distributed.run job, relay its stdout (rank 0's single JSON line) and return its rc.
+    Runs before this process has imported torch or touched the GPU; it never execs."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+    out, _ = proc.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    rest = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip() and not ln.strip().startswith("{")]
+    for ln in rest:                                        # launcher chatter is not part of the contract
+        print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode == 0 and not lines:
+        print("bench.py: ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def _stats(ts):
+    ts = sorted(ts)
+    return ts[0], ts[len(ts) // 2]
+
+
+def cpu_baseline(n: int, budget_s: float, data: str):
+    """Oracle (kind "port") on a bounded sample of the same workload: single thread like the
+    reference's main.cpp, then all host cores; >= 3 repetitions each, min and median."""
     import oracle
 
     A = oracle.dn(n)
-    rng = np.random.default_rng(0x5EED)
     probe_rods = 64
-    X = np.asfortranarray(rng.uniform(-1, 1, size=(probe_rods * 4, n)).T)
-    oracle.apply(A, X)                                    # warm
-    t0 = time.perf_counter(); oracle.apply(A, X); t = time.perf_counter() - t0
+    Xp = host_panel(n, probe_rods, data, 0x5EED)
+    oracle.apply(A, Xp)                                   # warm
+    t0 = time.perf_counter(); oracle.apply(A, Xp); t = time.perf_counter() - t0
     rate = probe_rods / max(t, 1e-9)
-    rods = int(min(max(rate * budget_s * 0.45, probe_rods), 32768))
-    X = np.asfortranarray(rng.uniform(-1, 1, size=(rods * 4, n)).T)
-    best = float("inf")
-    reps = 2
+    reps = 3
+    rods = int(min(max(rate * budget_s * 0.6 / reps, probe_rods), 32768))
+    X = host_panel(n, rods, data, 0x5EED)
+    t1 = []
     for _ in range(reps):
-        t0 = time.perf_counter(); oracle.apply(A, X); best = min(best, time.perf_counter() - t0)
+        t0 = time.perf_counter(); oracle.apply(A, X); t1.append(time.perf_counter() - t0)
     threads = oracle.max_threads()
-    t0 = time.perf_counter(); oracle.apply(A, X, threads=0); t_mt = time.perf_counter() - t0
+    # all cores: a sample `threads/2` times larger so that a repetition is not shorter than the fork/join noise
+    rods_mt = int(min(rods * max(threads // 2, 1), 65536, (512 << 20) // (32 * n)))
+    Xm = host_panel(n, rods_mt, data, 0x5EED)
+    oracle.apply(A, Xm, threads=0)                        # warm the thread pool
+    tm = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); oracle.apply(A, Xm, threads=0); tm.append(time.perf_counter() - t0)
+    b1, m1 = _stats(t1)
+    bm, mm = _stats(tm)
     return {
-        "value": rods / best, "unit": "rod-states/s", "cores": 1, "kind": "port",
-        "sample": f"oracle/sri_oracle.c single thread, {rods} rods x 4 cols at N={n}, best of {reps}",
-        "all_cores_value": rods / t_mt, "all_cores": threads,
+        "value": rods / b1, "unit": "rod-states/s", "cores": 1, "kind": "port",
+        "sample": f"oracle/sri_oracle.c single thread, {rods} rods x 4 cols at N={n}, {data} panels, "
+                  f"min of {reps} (median in median_value)",
+        "median_value": rods / m1, "reps": reps,
+        "all_cores_value": rods_mt / bm, "all_cores_median_value": rods_mt / mm, "all_cores": threads,
+        "all_cores_sample": f"{rods_mt} rods, OpenMP over column blocks, min of {reps}",
     }
+
+
+def host_panel(n: int, rods: int, data: str, seed: int) -> np.ndarray:
+    """Column-major n x (4*rods) synthetic panel on the host (cpu_baseline sample)."""
+    rng = np.random.default_rng(seed)
+    if data == "uniform":
+        return np.asfortranarray(rng.uniform(-1, 1, size=(rods * 4, n)).T)
+    x = 0.5 * (1 + np.cos(np.pi * np.arange(n) / (n - 1)))
+    t = 2 * x - 1
+    P = np.stack([np.ones_like(t), t, 0.5 * (3 * t * t - 1)], axis=1)
+    qe = rng.uniform(-2.0, 2.0, size=(rods, 3, 3))
+    K = np.einsum("ne,rae->ran", P, qe)                                    # rod, comp, node
+    fourth = np.cos(np.sqrt((K * K).sum(axis=1, keepdims=True)))
+    return np.asfortranarray(np.concatenate([K, fourth], axis=1).reshape(rods * 4, n).T)
+
+
+def device_panel(torch, n: int, rows: int, rods: int, data: str, seed: int, dev):
+    """(4*rods, rows) torch panel = column-major rows x 4*rods, generated on the device.
+
+    rod: per rod qe ~ U[-2,2)^9 (3 strain components x 3 Legendre modes, utilities.h:49-67), K(X_i) =
+    Phi(X_i) qe at the first `rows` Chebyshev nodes (chebyshev_differentiation.h:26), 4th column cos|K|."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    if data == "uniform":
+        return torch.rand((4 * rods, rows), dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    j = torch.arange(rows, dtype=torch.float64, device=dev)
+    t = torch.cos(torch.pi * j / (n - 1))                                   # 2x - 1 at the nodes
+    P = torch.stack([torch.ones_like(t), t, 0.5 * (3 * t * t - 1)], dim=0)  # 3 x rows
+    X = torch.empty((rods, 4, rows), dtype=torch.float64, device=dev)
+    step = 16384
+    for r0 in range(0, rods, step):
+        r1 = min(r0 + step, rods)
+        qe = torch.rand((r1 - r0, 3, 3), dtype=torch.float64, device=dev, generator=g) * 4 - 2
+        K = qe @ P                                                          # rod, comp, node
+        X[r0:r1, :3] = K
+        X[r0:r1, 3] = torch.cos(torch.linalg.vector_norm(K, dim=1))
+    return X.reshape(4 * rods, rows)
 
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))     # before torch / the GPU are touched
+
+    import torch
+
     # Libraries (RCCL's version banner, ...) write to stdout; the contract is ONE JSON line there.  Route
     # fd 1 to stderr until the result is printed.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # SRI_BENCH_REHEARSAL=1: rehearse N > 1 on a ONE-GPU box — every rank uses cuda:0 and the collectives are
     # staged through CPU tensors over gloo (RCCL refuses two ranks on one device).  Timings are meaningless
@@ -124,11 +239,18 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    comm_box = [None]                                       # the C ABI's RCCL communicator (created below)
+
     def all_gather(out, inp):
         if rehearsal:
             tmp = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(tmp, inp.cpu())
             out.copy_(tmp)
+        elif comm_box[0] is not None:
+            if inp.dim() == 1:
+                comm_box[0].allgather_tips(inp, out=out)     # sri_allgather_tips on torch's current stream
+            else:
+                comm_box[0].allgather_panel(inp, out=out)    # sri_allgather_panel
         else:
             dist.all_gather_into_tensor(out, inp)
 
@@ -141,10 +263,33 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
-    from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel
 
     if not os.path.exists(sri.library_path()):
         raise SystemExit("libsri_hip.so missing: run __graft_entry__.build() first (no CPU fallback)")
+
+    # The data-path exchange goes through the product's C ABI (sri_comm_*: RCCL called from C++ on the launch
+    # stream); torch.distributed keeps the contract's barrier / max-over-ranks plumbing and ships the 128-byte
+    # rendezvous token.  If the communicator cannot be created on EVERY rank, all ranks use torch's RCCL instead
+    # and the line says so.
+    collective = "none"
+    if use_dist and rehearsal:
+        collective = "gloo rehearsal (CPU staging)"
+    elif use_dist and args.collective == "torch":
+        collective = "torch.distributed (RCCL)"
+    elif use_dist:
+        from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel
+        err = ""
+        try:
+            comm_box[0] = parallel.Communicator.from_torch_distributed(local_rank)
+        except Exception as e:                              # noqa: BLE001 — reported in the result line
+            err = str(e)
+        okf = torch.tensor([1.0 if comm_box[0] is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if okf.item() == 1.0:
+            collective = "sri_comm (libsri_hip.so: RCCL from C++)"
+        else:
+            comm_box[0] = None
+            collective = "torch.distributed (RCCL); sri_comm unavailable" + (f": {err}" if err else " on another rank")
 
     n, rods = args.n, args.rods
     which = sri.OP_DN if args.operator == "dn" else sri.OP_DNN_INV
@@ -155,9 +300,10 @@ def main():
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         op.set_max_workgroups(max(cus - reserve, 1))
 
-    g = torch.Generator(device=dev).manual_seed(0x5EED + rank)
-    X = torch.rand((M, rows), dtype=torch.float64, device=dev, generator=g) * 2 - 1   # synthetic U[-1,1) panel
-    Y = torch.empty_like(X)
+    nrot = max(args.rotate, 1)
+    Xs = [device_panel(torch, n, rows, rods, args.data, 0x5EED + rank + 1000 * r, dev) for r in range(nrot)]
+    Ys = [torch.empty_like(Xs[0]) for _ in range(nrot)]
+    X, Y = Xs[0], Ys[0]
 
     # exchange step (N > 1): tips of step i gathered on a side stream under the apply of step i+1
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
@@ -169,12 +315,13 @@ def main():
 
     def step(i: int, ev_pair=None):
         b = i & 1
+        Xi, Yi = Xs[i % nrot], Ys[i % nrot]
         tip_mode = use_dist and args.gather in ("tip", "final")
         if use_dist and args.gather == "tip":
             torch.cuda.current_stream().wait_event(gathered[b])       # tip buffer b free again
         if ev_pair is not None:
             ev_pair[0].record()
-        op.apply(X, out=Y, tips=tips_local[b] if tip_mode else None)  # the epilogue emits the tip state itself
+        op.apply(Xi, out=Yi, tips=tips_local[b] if tip_mode else None)  # the epilogue emits the tip state itself
         if ev_pair is not None:
             ev_pair[1].record()
         if use_dist and args.gather == "tip":
@@ -184,7 +331,7 @@ def main():
                 all_gather(tips_all[b], tips_local[b])
                 gathered[b].record()
         elif use_dist and args.gather == "full":
-            all_gather(full_all, Y)
+            all_gather(full_all, Yi)
 
     def fence():
         torch.cuda.synchronize()
@@ -217,6 +364,7 @@ def main():
     if use_dist:
         all_reduce_max(t)
     elapsed, kernel_ms = float(t[0]), float(t[1])
+    Xl, Yl = Xs[(args.steps - 1) % nrot], Ys[(args.steps - 1) % nrot]     # the panels of the last step
 
     # optional: one full-panel all-gather timed on its own (reported, never part of `value`)
     full_gather_ms = None
@@ -230,8 +378,8 @@ def main():
         tip_gather_ms = (time.perf_counter() - t1) * 1e3 / 10
         try:
             buf = torch.empty((M * world, rows), dtype=torch.float64, device=dev)
-            all_gather(buf, Y); fence()
-            t1 = time.perf_counter(); all_gather(buf, Y); fence()
+            all_gather(buf, Yl); fence()
+            t1 = time.perf_counter(); all_gather(buf, Yl); fence()
             full_gather_ms = (time.perf_counter() - t1) * 1e3
             del buf
         except Exception:
@@ -242,17 +390,17 @@ def main():
         import oracle
         A = oracle.dn(n) if which == sri.OP_DN else oracle.integration(n)[0]
         idx = torch.arange(0, M, max(M // 256, 1), device=dev)[:256]
-        Xs = np.asfortranarray(X[idx].cpu().numpy().T)
-        Ys = np.asfortranarray(Y[idx].cpu().numpy().T)
-        Yr = oracle.apply(A, Xs, threads=0)
-        verify = float(np.linalg.norm(Ys - Yr) / np.linalg.norm(Yr))
+        Xh = np.asfortranarray(Xl[idx].cpu().numpy().T)
+        Yh = np.asfortranarray(Yl[idx].cpu().numpy().T)
+        Yr = oracle.apply(A, Xh, threads=0)
+        verify = float(np.linalg.norm(Yh - Yr) / np.linalg.norm(Yr))
 
     gather_ok = None
     if use_dist and args.gather in ("tip", "final"):
         # every rank's slab of the gathered state must equal that rank's own tips (checked on every rank, reduced)
         b_last = (args.steps - 1) & 1
         mine = tips_all[b_last][rank * M:(rank + 1) * M]
-        ok = torch.tensor([1.0 if torch.equal(mine, Y[:, 0].contiguous()) else 0.0], dtype=torch.float64, device=dev)
+        ok = torch.tensor([1.0 if torch.equal(mine, Yl[:, 0].contiguous()) else 0.0], dtype=torch.float64, device=dev)
         neg = -ok
         all_reduce_max(neg)                                 # max of negatives = -(min of ok)
         gather_ok = bool(-neg.item() == 1.0)
@@ -262,25 +410,37 @@ def main():
         flops = 8.0 * rows * rows * rods                    # per launch, algorithmic
         alg_bytes = 64.0 * rows * rods + 8.0 * rows * rows
         achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(tp):
+        # HBM traffic is a PMC measurement (rocprofv3 --pmc, separate passes) that cannot be taken inside this
+        # process: the committed summary of tools/profile_bench.sh for the same shape is replayed and labelled.
+        traffic, traffic_source = None, None
+        for name in (f"hbm_traffic_n{n}_r{rods}_{args.operator}.json", "hbm_traffic_latest.json"):
+            tp = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(tp):
+                continue
             try:
                 rec = json.load(open(tp))
                 if rec.get("n") == n and rec.get("rods") == rods and rec.get("operator") == args.operator:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of tools/profile_bench.sh" \
+                                     f"{', ' + rec['date'] if rec.get('date') else ''}; not measured in this run)"
+                    break
             except Exception:
                 traffic = None
+        config_id = next((c for c, (cn, cr) in CONFIGS.items() if (cn, cr) == (n, rods) and (c == 4) == (world == 8)), None)
         out = {
             "metric": "rod-states/sec (D_N.X apply, fp64) at N=256; % MI355X fp64 MFMA peak" if (n == 256 and which == sri.OP_DN)
                       else f"rod-states/sec ({args.operator} apply, fp64) at N={n}",
             "value": value, "unit": "rod-states/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"N={n}, batch={rods} rods x 4 state columns per GPU, fp64, {args.operator} apply"
+            "config": {"workload": f"N={n}, batch={rods} rods x 4 state columns per GPU, fp64, {args.operator} apply, "
+                                   + ("synthetic rod-strain fields" if args.data == "rod" else "uniform U[-1,1) panels")
                                    + (f", {world} GPUs sharded on the batch axis, RCCL all-gather of {args.gather} state" if use_dist else ""),
+                       "baseline_config": config_id,
                        "N": n, "rods_per_gpu": rods, "state_columns": 4, "operator": args.operator,
+                       "panel_data": args.data, "panel_pairs_rotated": nrot,
                        "kernel": op.last_kernel, "gather": args.gather if use_dist else "none",
+                       "collective": collective,
                        "clock_ramp_ms_untimed": args.ramp_ms,
                        "cus_reserved_for_collective": reserve},
             # AI = N/8 flop/B against the machine balance 78.6 TF / 8 TB/s = 9.8 flop/B: HBM-bound below N ~ 79
@@ -289,7 +449,7 @@ def main():
                          if n / 8.0 >= PEAK_FP64_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS else
                          {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}) |
-                        {"traffic": traffic, "achieved_TFLOPs": achieved_tf,
+                        {"traffic": traffic, "traffic_source": traffic_source, "achieved_TFLOPs": achieved_tf,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
@@ -304,7 +464,7 @@ def main():
         if gather_ok is not None:
             out["gathered_state_verified"] = gather_ok
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, args.data)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -64,6 +64,14 @@ C_ABI = {
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
     "sri_rod_integrate_positions": (_int, [_vp, _vp, _sz, _sz, _dp, _vp, _sz, _vp]),
     "sri_rod_integrate": (_int, [_vp, _vp, _sz, _dp, _dp, _vp, _sz, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
+    "sri_comm_unique_id": (_int, [_vp]),
+    "sri_comm_create": (_int, [C.POINTER(_vp), _vp, _int, _int, _int]),
+    "sri_comm_destroy": (_int, [_vp]),
+    "sri_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "sri_allgather_tips": (_int, [_vp, _vp, _sz, _vp, C.POINTER(_sz), _vp]),
+    "sri_allgather_panel": (_int, [_vp, _vp, _sz, _sz, _vp, C.POINTER(_sz), _vp]),
+    "sri_last_rccl_error": (_int, []),
+    "sri_rccl_strerror": (C.c_char_p, [_int]),
     "sri_apply_last_kernel": (C.c_char_p, [_vp]),
     "sri_strerror": (C.c_char_p, [_int]),
     "sri_last_hip_error": (_int, []),
@@ -80,6 +88,9 @@ class SriError(RuntimeError):
             msg = _lib.sri_strerror(status).decode()
             if status == -4:
                 msg += f" (hipError {_lib.sri_last_hip_error()})"
+            if status == -8:
+                e = _lib.sri_last_rccl_error()
+                msg += f" (ncclResult {e}: {_lib.sri_rccl_strerror(e).decode()})"
         super().__init__(f"{what}: {msg} [sri_status {status}]")
 
 

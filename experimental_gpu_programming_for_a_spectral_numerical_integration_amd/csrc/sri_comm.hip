@@ -1,0 +1,199 @@
+// sri_comm.hip — the ONE exchange step of the multi-GPU path (SURVEY.md §8e, §8b `sri_allgather`): reassembling the
+// integrated state of a rod batch that was sharded by columns over the GPUs of one node.  RCCL over xGMI, called from
+// C++ on the caller's HIP stream, so that a C++ host program (the reference's main.cpp is C++) needs neither Python nor
+// torch.distributed.  The apply itself never communicates: rods are independent and the operator is replicated.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 on first use): single-GPU users of libsri_hip.so do not load the
+// 570 MB collective library, and a process that already holds RCCL (PyTorch's bundled copy) shares that instance.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "sri_internal.h"
+
+namespace {
+
+struct Rccl {
+  void* so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+std::once_flag g_once;
+Rccl g_rccl;
+thread_local int g_last_rccl = 0;
+
+template <typename F>
+bool bind(void* so, const char* name, F& fn) {
+  fn = reinterpret_cast<F>(dlsym(so, name));
+  return fn != nullptr;
+}
+
+const Rccl& rccl() {
+  std::call_once(g_once, [] {
+    Rccl& r = g_rccl;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.so) break;
+    }
+    if (!r.so) return;
+    r.ok = bind(r.so, "ncclGetUniqueId", r.GetUniqueId) && bind(r.so, "ncclCommInitRank", r.CommInitRank) &&
+           bind(r.so, "ncclCommDestroy", r.CommDestroy) && bind(r.so, "ncclAllGather", r.AllGather) &&
+           bind(r.so, "ncclBroadcast", r.Broadcast) && bind(r.so, "ncclGroupStart", r.GroupStart) &&
+           bind(r.so, "ncclGroupEnd", r.GroupEnd) && bind(r.so, "ncclGetErrorString", r.GetErrorString);
+  });
+  return g_rccl;
+}
+
+int fail(ncclResult_t e) {
+  g_last_rccl = static_cast<int>(e);
+  return SRI_ECOMM;
+}
+
+}  // namespace
+
+struct sri_comm_handle {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+extern "C" {
+
+int sri_comm_unique_id(void* id) {
+  if (!id) return SRI_EINVAL;
+  static_assert(SRI_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "sri_capi.h must mirror RCCL's unique-id size");
+  const Rccl& r = rccl();
+  if (!r.ok) return SRI_EUNSUPPORTED;
+  ncclUniqueId u;
+  ncclResult_t e = r.GetUniqueId(&u);
+  if (e != ncclSuccess) return fail(e);
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return SRI_OK;
+}
+
+int sri_comm_create(sri_comm_t** out, const void* id, int rank, int world, int device) {
+  if (!out) return SRI_EINVAL;
+  *out = nullptr;
+  if (!id || world < 1 || rank < 0 || rank >= world) return SRI_EINVAL;
+  int count = 0;
+  hipError_t he = hipGetDeviceCount(&count);
+  if (he != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    if (he != hipSuccess) sri::record_hip_error(static_cast<int>(he));
+    return SRI_ENODEVICE;
+  }
+  const Rccl& r = rccl();
+  if (!r.ok) return SRI_EUNSUPPORTED;
+  he = hipSetDevice(device);
+  if (he != hipSuccess) {
+    sri::record_hip_error(static_cast<int>(he));
+    return SRI_EHIP;
+  }
+  sri_comm_handle* h = new (std::nothrow) sri_comm_handle;
+  if (!h) return SRI_ENOMEM;
+  h->rank = rank;
+  h->world = world;
+  h->device = device;
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t e = r.CommInitRank(&h->comm, world, u, rank);     // collective over all `world` callers
+  if (e != ncclSuccess) {
+    delete h;
+    return fail(e);
+  }
+  *out = h;
+  return SRI_OK;
+}
+
+int sri_comm_destroy(sri_comm_t* h) {
+  if (!h) return SRI_OK;
+  int rc = SRI_OK;
+  if (h->comm) {
+    ncclResult_t e = rccl().CommDestroy(h->comm);
+    if (e != ncclSuccess) rc = fail(e);
+  }
+  delete h;
+  return rc;
+}
+
+int sri_comm_rank(const sri_comm_t* h, int* rank, int* world) {
+  if (!h) return SRI_EINVAL;
+  if (rank) *rank = h->rank;
+  if (world) *world = h->world;
+  return SRI_OK;
+}
+
+// Gather `counts[r]` doubles from every rank r into d_all at offset sum(counts[0..r)).  counts == nullptr: every
+// rank contributes `count_local` (one ncclAllGather).  Ragged shards (rods % world != 0, parallel.shard_columns) are
+// one group of per-root broadcasts — RCCL fuses the group into one launch.
+static int allgather_doubles(sri_comm_t* h, const double* d_local, size_t count_local, double* d_all, const size_t* counts,
+                             void* stream) {
+  if (!h || !h->comm || !d_all || (!d_local && count_local)) return SRI_EINVAL;
+  const Rccl& r = rccl();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bool equal = true;
+  if (counts) {
+    if (counts[h->rank] != count_local) return SRI_EINVAL;
+    for (int i = 0; i < h->world; ++i) equal = equal && counts[i] == count_local;
+    // SRI_COMM_FORCE_RAGGED=1 sends even shards down the ragged route (lets a one- or two-GPU box test it)
+    static const bool force_ragged = [] { const char* v = getenv("SRI_COMM_FORCE_RAGGED"); return v && v[0] == '1'; }();
+    if (force_ragged) equal = false;
+  }
+  ncclResult_t e;
+  if (equal) {
+    if (count_local == 0) return SRI_OK;
+    e = r.AllGather(d_local, d_all, count_local, ncclDouble, h->comm, s);
+    return e == ncclSuccess ? SRI_OK : fail(e);
+  }
+  e = r.GroupStart();
+  if (e != ncclSuccess) return fail(e);
+  size_t off = 0;
+  ncclResult_t first_bad = ncclSuccess;
+  for (int root = 0; root < h->world; ++root) {
+    if (counts[root]) {
+      e = r.Broadcast(root == h->rank ? d_local : d_all + off, d_all + off, counts[root], ncclDouble, root, h->comm, s);
+      if (e != ncclSuccess && first_bad == ncclSuccess) first_bad = e;
+    }
+    off += counts[root];
+  }
+  e = r.GroupEnd();
+  if (first_bad != ncclSuccess) return fail(first_bad);
+  return e == ncclSuccess ? SRI_OK : fail(e);
+}
+
+int sri_allgather_tips(sri_comm_t* h, const double* d_tips_local, size_t columns_local, double* d_tips_all,
+                       const size_t* columns_per_rank, void* hip_stream) {
+  return allgather_doubles(h, d_tips_local, columns_local, d_tips_all, columns_per_rank, hip_stream);
+}
+
+int sri_allgather_panel(sri_comm_t* h, const double* dY_local, size_t rows, size_t columns_local, double* dY_all,
+                        const size_t* columns_per_rank, void* hip_stream) {
+  if (!h || rows == 0) return SRI_EINVAL;
+  if (!columns_per_rank) return allgather_doubles(h, dY_local, rows * columns_local, dY_all, nullptr, hip_stream);
+  std::vector<size_t> counts(static_cast<size_t>(h->world));
+  for (int i = 0; i < h->world; ++i) counts[static_cast<size_t>(i)] = rows * columns_per_rank[i];
+  return allgather_doubles(h, dY_local, rows * columns_local, dY_all, counts.data(), hip_stream);
+}
+
+int sri_last_rccl_error(void) { return g_last_rccl; }
+
+const char* sri_rccl_strerror(int rccl_result) {
+  const Rccl& r = rccl();
+  return r.ok ? r.GetErrorString(static_cast<ncclResult_t>(rccl_result)) : "RCCL not loaded";
+}
+
+}  // extern "C"

@@ -216,6 +216,7 @@ const char* sri_strerror(int status) {
     case SRI_ENODEVICE: return "no usable HIP device";
     case SRI_EUNSUPPORTED: return "unsupported request";
     case SRI_ENOTCONVERGED: return "fixed-point iteration did not converge";
+    case SRI_ECOMM: return "RCCL error";
     default: return "unknown sri_status";
   }
 }

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRI_ABI_VERSION 1
+#define SRI_ABI_VERSION 2
 
 typedef enum sri_status {
     SRI_OK = 0,
@@ -40,7 +40,8 @@ typedef enum sri_status {
     SRI_EHIP = -4,         /* a HIP runtime call failed (sri_last_hip_error() has the code)   */
     SRI_ENODEVICE = -5,    /* no gfx950 device / bad device ordinal                           */
     SRI_EUNSUPPORTED = -6, /* valid request this build cannot serve                           */
-    SRI_ENOTCONVERGED = -7 /* sri_rod_integrate_quaternions: update still above tol at max_iter */
+    SRI_ENOTCONVERGED = -7,/* sri_rod_integrate_quaternions: update still above tol at max_iter */
+    SRI_ECOMM = -8         /* an RCCL call failed (sri_last_rccl_error() has the ncclResult_t)   */
 } sri_status;
 
 /* Which constant left-hand matrix an apply handle holds. */
@@ -208,6 +209,42 @@ int sri_rod_integrate_positions(sri_rod_t *h, const double *dQ, size_t ldq, size
 int sri_rod_integrate(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, const double *r_init,
                       double *dQ, size_t ldq, double *dR, size_t ldr, double tol, uint32_t max_iter,
                       uint32_t *iters, double *last_update, void *hip_stream);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Multi-GPU: the one exchange step (the `sri_allgather` of §8b).  The rod batch */
+/* shards by columns over the GPUs of a node — one process (or thread) per GPU, each with its   */
+/* own sri_apply_t; the apply never communicates.  A communicator reassembles results with an   */
+/* RCCL all-gather over xGMI, enqueued on the caller's HIP stream.  The reference has no        */
+/* counterpart (main.cpp:181-205 is one thread, one rod); a C++ caller uses it as:              */
+/*   rank 0: sri_comm_unique_id(id); ship the 128 bytes to the other ranks out of band          */
+/*   all:    sri_comm_create(&c, id, rank, world, device);   (collective)                       */
+/*           sri_apply_tips(...); sri_allgather_tips(c, d_tips, M_local, d_all, NULL, stream);   */
+/* RCCL is loaded on first use (dlopen librccl.so.1); SRI_EUNSUPPORTED if it cannot be found.   */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct sri_comm_handle sri_comm_t;
+#define SRI_COMM_ID_BYTES 128
+
+/* A fresh rendezvous token (ncclUniqueId), SRI_COMM_ID_BYTES bytes, produced by ONE rank. */
+int sri_comm_unique_id(void *id);
+
+/* Join the communicator `id` as `rank` of `world` on HIP device `device`; every rank must call. */
+int sri_comm_create(sri_comm_t **out, const void *id, int rank, int world, int device);
+int sri_comm_destroy(sri_comm_t *c);
+int sri_comm_rank(const sri_comm_t *c, int *rank, int *world);
+
+/* All-gather the tip-node value of every column (what sri_apply_tips / sri_integrate_tips emit): rank r's
+ * `columns_local` doubles land in d_tips_all at the offset of its shard, rank order.  columns_per_rank: `world`
+ * entries (ragged shards, rods % world != 0) or NULL when every rank holds columns_local. */
+int sri_allgather_tips(sri_comm_t *c, const double *d_tips_local, size_t columns_local, double *d_tips_all,
+                       const size_t *columns_per_rank, void *hip_stream);
+
+/* All-gather whole output slabs: panels are column-major with leading dimension == rows, so every rank's slab is one
+ * contiguous block and dY_all IS the global rows x (sum of columns) panel. */
+int sri_allgather_panel(sri_comm_t *c, const double *dY_local, size_t rows, size_t columns_local, double *dY_all,
+                        const size_t *columns_per_rank, void *hip_stream);
+
+int sri_last_rccl_error(void);
+const char *sri_rccl_strerror(int rccl_result);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Introspection / diagnostics                                                              */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(sri):
         assert hasattr(lib, name), f"{name} declared in include/sri_capi.h but not exported"
     # and the Python binding table covers exactly the header
     assert sorted(sri.C_ABI) == names
-    assert sri.load_library().sri_abi_version() == 1
+    assert sri.load_library().sri_abi_version() == 2
 
 
 def test_library_is_gfx950_only(sri):
@@ -129,3 +129,24 @@ def test_chebyshev_interpolation_matrix(sri, n_from, n_to):
     if n_from == n_to:
         assert np.array_equal(P, np.eye(n_to))
     assert P[0, 0] == 1.0 and P[-1, -1] == 1.0                   # both grids share the end points X = 1 and X = 0
+
+
+def test_comm_entry_points_validate_without_a_gpu(sri):
+    """sri_comm_* (csrc/sri_comm.hip): argument errors first, then SRI_ENODEVICE on a box without a GPU — never a crash,
+    and RCCL is not even loaded for it."""
+    import ctypes as C
+
+    lib = sri.load_library()
+    h = C.c_void_p()
+    buf = C.create_string_buffer(128)
+    assert lib.sri_comm_create(C.byref(h), None, 0, 1, 0) == -1
+    assert lib.sri_comm_create(C.byref(h), buf, 2, 2, 0) == -1
+    assert lib.sri_comm_create(C.byref(h), buf, 0, 0, 0) == -1
+    assert lib.sri_comm_unique_id(None) == -1
+    assert lib.sri_comm_destroy(None) == 0
+    assert lib.sri_allgather_tips(None, None, 0, None, None, None) == -1
+    assert lib.sri_allgather_panel(None, None, 4, 0, None, None, None) == -1
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.sri_comm_create(C.byref(h), buf, 0, 1, 0) == -5 and not h.value
+    assert sri.load_library().sri_strerror(-8) == b"RCCL error"

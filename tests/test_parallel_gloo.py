@@ -48,10 +48,19 @@ def _worker(rank, world, port, n, rods, q):
         first, count = parallel.shard_columns(M, world, rank, granule=4)
         Xl = Xg[first:first + count]
         Yl = torch.from_numpy(np.ascontiguousarray(oracle.apply(A, np.asfortranarray(Xl.T)).T))
-        tips, _ = parallel.gather_tip_state(Yl)
-        full, _ = parallel.gather_panel(Yl)
-        tips_async, work = parallel.gather_tip_state(Yl, async_op=True)
-        work.wait()
+        counts = parallel.shard_counts(M, world, granule=4)
+        ragged = len(set(counts)) > 1
+        tips, _ = parallel.gather_tip_state(Yl, columns_per_rank=counts)
+        full, _ = parallel.gather_panel(Yl, columns_per_rank=counts)
+        if ragged:
+            # ragged shards without the per-rank counts must be refused up front, not hang in the collective
+            tips_async = tips
+            out = torch.empty(M, dtype=torch.float64)
+            t2, _ = parallel.gather_tip_state(Yl, out=out, columns_per_rank=counts)
+            assert t2 is out and torch.equal(out, tips)
+        else:
+            tips_async, work = parallel.gather_tip_state(Yl, async_op=True)
+            work.wait()
         if rank == 0:
             Yg = oracle.apply(A, np.asfortranarray(Xg.T)).T
             ok = (np.array_equal(full.numpy(), Yg) and np.array_equal(tips.numpy(), Yg[:, 0])
@@ -61,14 +70,20 @@ def _worker(rank, world, port, n, rods, q):
         dist.destroy_process_group()
 
 
-def test_sharded_apply_reassembles_over_gloo():
+@pytest.mark.parametrize("rods", [6, 7])          # 7 rods over 2 ranks: ragged shards (4 + 3 rods)
+def test_sharded_apply_reassembles_over_gloo(rods):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 16, 6, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 16, rods, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_ragged_gather_needs_counts():
+    assert parallel.shard_counts(28, 2, granule=4) == [16, 12]
+    assert parallel.shard_counts(24, 2, granule=4) == [12, 12]
