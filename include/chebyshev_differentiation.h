@@ -15,7 +15,8 @@
  *     include/sri_capi.h), not in the header; values are bit-identical to the reference's formulas;
  *   - no fixed-size N x N temporaries, so N is not limited by Eigen's stack-allocation limit
  *     (the reference's getDn stops compiling near N = 128);
- *   - it includes the standard headers it needs itself;
+ *   - it includes the standard headers it needs itself, and <iostream> like the reference header (h:11) because
+ *     main.cpp:198,202 use std::cout without an include of their own;
  *   - when <Eigen/Dense> is not installed, getDn returns sri::DenseMatrix, a minimal column-major
  *     owner with the accessors main.cpp-style code needs ((i,j), rows(), cols(), data());
  *   - sri::SpectralApply is a small RAII wrapper of the device apply (main.cpp:172 batched).
@@ -23,8 +24,14 @@
 #ifndef CHEBYSHEV_DIFFERENTIATION_H
 #define CHEBYSHEV_DIFFERENTIATION_H
 
+// <iostream> is what the reference header itself includes (reference h:11) and main.cpp relies on it transitively
+// (std::cout at main.cpp:198,202); <array>, <algorithm>, <cmath> are the headers the reference header uses without
+// including them (std::array h:20, std::generate h:25, cos / pow / M_PI h:26,48).
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstddef>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <vector>

@@ -15,7 +15,23 @@ absent) and it ships no tests or vectors ("parity unpinned").  The fi
                        host (regression pin for the C++ host formers; N <= 64 is insensitive to a
                        1-ulp libm difference: 1.8e-13).
 
-Run:  python tests/golden/make_golden.py      (needs mpmath; takes a few seconds)
+  dn_exact_mp_large.npz the same independent 60-digit evaluation at the sizes the metric is quoted on
+                       (`--large`, minutes):  N=256: full D, full Dn_NN^-1 (mp LU), x[];  N=1024: x[], 16 full
+                       rows of D, its diagonal, and 12 columns + 12 rows of the exact Dn_NN^-1 obtained by
+                       iterative refinement in 60-digit arithmetic (residual against the exact-math Dn_NN in mp,
+                       correction with an fp64 inverse; contraction ~1e-10 per sweep, 5 sweeps).
+  pdf_appendix_b.json  the two matrices PRINTED in the reference's own documentation
+                       (/root/reference/materials/rod_modeling.pdf, eq. B.7 and B.12, on [-1, 1]) — the only
+                       numerical values the reference tree holds for this path, typed in from the PDF.
+
+  config1_stdout.txt   stdout of the reference's own, UNMODIFIED /root/reference/main.cpp compiled in place against
+                       this repo's drop-in header, libsri_hip.so and the stand-in headers under compat/
+                       (`--stdout`; tests/test_reference_main.py rebuilds it and compares).  Product output, checked
+                       there against config1_anchors.json and the oracle — not a pin of the oracle.
+
+Run:  python tests/golden/make_golden.py           (needs mpmath; takes a few seconds)
+      python tests/golden/make_golden.py --stdout  (config1_stdout.txt; needs /root/reference and a built libsri_hip.so)
+      python tests/golden/make_golden.py --large   (additionally dn_exact_mp_large.npz; ~10 min on 8 cores)
 """
 import json
 import os
@@ -46,8 +62,101 @@ def dn_exact(n: int, digits: int = 60):
     return to_np(D), to_np(Dinv), np.array([float(v) for v in x])
 
 
+def _mp_setup(n, digits=60):
+    import mpmath as mp
+
+    mp.mp.dps = digits
+    x = [(1 + mp.cos(mp.pi * j / (n - 1))) / 2 for j in range(n)]
+    c = [(2 if j in (0, n - 1) else 1) * (-1) ** j for j in range(n)]
+    return mp, x, c
+
+
+def _mp_row(mp, x, c, i):
+    """Row i of the exact D_N (eq. B.16 off the diagonal, negative row sum on it) as a list of mpf."""
+    n = len(x)
+    row = [mp.mpf(0)] * n
+    for j in range(n):
+        if j != i:
+            row[j] = mp.mpf(c[i]) / c[j] / (x[i] - x[j])
+    row[i] = -mp.fsum(row)
+    return row
+
+
+def _refine_worker(args):
+    """Exact column (kind 'c') or row (kind 'r') `idx` of Dn_NN^-1 at N = n by iterative refinement in mp."""
+    n, kind, idx, z0, Dinv64 = args
+    mp, x, c = _mp_setup(n)
+    m = n - 1
+    rows = [_mp_row(mp, x, c, i)[:m] for i in range(m)]                      # exact-math Dn_NN
+    if kind == "r":                                                          # rows of the inverse: solve Dnn^T y = e_idx
+        rows = [[rows[i][j] for i in range(m)] for j in range(m)]
+        Dinv64 = Dinv64.T
+    z = [mp.mpf(float(v)) for v in z0]
+    for _ in range(5):
+        res = [(1 if i == idx else 0) - mp.fdot(rows[i], z) for i in range(m)]
+        r64 = np.array([float(v) for v in res])
+        d = Dinv64 @ r64
+        z = [z[i] + mp.mpf(float(d[i])) for i in range(m)]
+    res = max(abs((1 if i == idx else 0) - mp.fdot(rows[i], z)) for i in range(m))
+    return kind, idx, np.array([float(v) for v in z]), float(res)
+
+
+def large():
+    """dn_exact_mp_large.npz (see the module docstring)."""
+    import multiprocessing as mpc
+
+    import oracle
+
+    out = {}
+    D, Dinv, x = dn_exact(256)
+    out["D256"], out["Dinv256"], out["x256"] = D, Dinv, x
+    n = 1024
+    mp, xs, c = _mp_setup(n)
+    out["x1024"] = np.array([float(v) for v in xs])
+    ridx = np.array([0, 1, 2, 3, 100, 255, 256, 511, 512, 700, 767, 1000, 1020, 1021, 1022, 1023])
+    out["D1024_row_idx"] = ridx
+    out["D1024_rows"] = np.array([[float(v) for v in _mp_row(mp, xs, c, int(i))] for i in ridx])
+    diag = []
+    for i in range(n):
+        diag.append(float(-mp.fsum(mp.mpf(c[i]) / c[j] / (xs[i] - xs[j]) for j in range(n) if j != i)))
+    out["D1024_diag"] = np.array(diag)
+    Dinv64, _ = oracle.integration(n)                                        # only the preconditioner / start of the refinement
+    cidx = np.array([0, 1, 2, 50, 255, 511, 512, 800, 1000, 1020, 1021, 1022])
+    jobs = [(n, "c", int(j), Dinv64[:, j].copy(), np.ascontiguousarray(Dinv64)) for j in cidx]
+    jobs += [(n, "r", int(i), Dinv64[i, :].copy(), np.ascontiguousarray(Dinv64)) for i in cidx]
+    with mpc.get_context("spawn").Pool(8) as pool:
+        res = pool.map(_refine_worker, jobs)
+    cols = {j: z for k, j, z, _ in res if k == "c"}
+    rws = {i: z for k, i, z, _ in res if k == "r"}
+    worst = max(r for _, _, _, r in res)
+    assert worst < 1e-40, worst                                              # the refinement converged to working precision
+    out["Dinv1024_idx"] = cidx
+    out["Dinv1024_cols"] = np.stack([cols[int(j)] for j in cidx], axis=1)
+    out["Dinv1024_rows"] = np.stack([rws[int(i)] for i in cidx], axis=0)
+    np.savez_compressed(os.path.join(HERE, "dn_exact_mp_large.npz"), **out)
+    print("dn_exact_mp_large.npz written; refinement residual", worst)
+
+
 def main():
     import oracle
+
+    if "--large" in sys.argv:
+        large()
+        return
+    if "--stdout" in sys.argv:
+        import subprocess
+        import tempfile
+
+        root = os.path.dirname(os.path.dirname(HERE))
+        sys.path.insert(0, os.path.join(root, "tests"))
+        from test_reference_main import build_reference_main
+
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = build_reference_main(tmp)
+            text = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+        open(os.path.join(HERE, "config1_stdout.txt"), "w").write(text)
+        print("config1_stdout.txt written")
+        return
 
     out = {}
     for n in (2, 3, 5, 8, 16, 33, 64):
@@ -85,6 +194,16 @@ def main():
                          "r": [0.56267255750165, 0, -0.74591365970371]},
         "nodes": [{"i": r[0], "q_w": r[1], "q_y": r[2], "r_x": r[3], "r_z": r[4]} for r in rows],
     }, open(os.path.join(HERE, "config1_anchors.json"), "w"), indent=1)
+    # materials/rod_modeling.pdf Appendix B as printed (domain [-1, 1]); the reference's domain is [0, 1] => x2
+    json.dump({
+        "source": "/root/reference/materials/rod_modeling.pdf, Appendix B — values printed in the document",
+        "domain": [-1, 1],
+        "eq_B7_D_two_nodes": [[0.5, -0.5], [0.5, -0.5]],
+        "eq_B12_D_three_nodes": [[1.5, -2.0, 0.5], [0.5, 0.0, -0.5], [-0.5, 2.0, -1.5]],
+        "eq_B14_corner": "d_00 = (2 n^2 + 1)/6 = -d_nn, n = N - 1",
+        "eq_B16_offdiag": "d_ij = (c_i/c_j) (-1)^(i+j) / (x_i - x_j)",
+        "scale_to_reference_domain_0_1": 2.0,
+    }, open(os.path.join(HERE, "pdf_appendix_b.json"), "w"), indent=1)
     print("golden fixtures written to", HERE)
 
 

@@ -56,6 +56,25 @@ def test_integration_matrix_matches_oracle(sri, oracle, n):
     assert np.array_equal(sri.ivp(b, np.array([1.0, 0, 0, 0])), oracle.ivp(d, np.array([1.0, 0, 0, 0])))
 
 
+def test_product_formers_against_independent_60_digit_evaluation(sri):
+    """The PRODUCT's host formers (not via the oracle) against the independent exact-maths fixtures at the sizes the
+    metric is quoted on — same gates as tests/test_oracle.py::test_large_grids_against_independent_60_digit_evaluation."""
+    g = np.load(os.path.join(GOLD, "dn_exact_mp_large.npz"))
+    fro = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert np.abs(sri.ComputeChebyshevPoints(256) - g["x256"]).max() <= 4e-16
+    assert np.abs(sri.ComputeChebyshevPoints(1024) - g["x1024"]).max() <= 4e-16
+    assert fro(sri.getDn(256), g["D256"]) <= 1.5e-12
+    assert fro(sri.integration_matrix(256)[0], g["Dinv256"]) <= 1e-13
+    D = sri.getDn(1024)
+    assert fro(D[g["D1024_row_idx"]], g["D1024_rows"]) <= 2e-11 and fro(np.diag(D), g["D1024_diag"]) <= 3e-11
+    Dinv = sri.integration_matrix(1024)[0]
+    idx = g["Dinv1024_idx"]
+    assert fro(Dinv[:, idx], g["Dinv1024_cols"]) <= 1e-12 and fro(Dinv[idx, :], g["Dinv1024_rows"]) <= 1e-12
+    small = np.load(os.path.join(GOLD, "dn_exact_mp.npz"))
+    for n in (16, 64):
+        assert fro(sri.getDn(n), small[f"D{n}"]) <= 2e-13 and fro(sri.integration_matrix(n)[0], small[f"Dinv{n}"]) <= 1e-12
+
+
 def test_host_formers_against_golden(sri):
     g = np.load(os.path.join(GOLD, "dn_oracle_n64.npz"))
     # N=64 entries move by <= 1.8e-13 under a 1-ulp libm difference (SURVEY Appendix B)

@@ -35,6 +35,15 @@ def test_dn_known_answers(oracle):
     assert np.allclose(oracle.dn(3), np.array([[3, -4, 1], [1, 0, -1], [-1, 4, -3]], dtype=float), atol=1e-15)
 
 
+def test_dn_against_the_matrices_printed_in_the_reference_documentation(oracle):
+    """tests/golden/pdf_appendix_b.json: eq. B.7 / B.12 of /root/reference/materials/rod_modeling.pdf as printed — the only
+    numerical values the reference tree itself holds for this path (a reference-held fixture, on [-1, 1])."""
+    pdf = json.load(open(os.path.join(GOLD, "pdf_appendix_b.json")))
+    scale = pdf["scale_to_reference_domain_0_1"]
+    assert np.array_equal(oracle.dn(2), scale * np.array(pdf["eq_B7_D_two_nodes"]))
+    assert np.allclose(oracle.dn(3), scale * np.array(pdf["eq_B12_D_three_nodes"]), rtol=0, atol=1e-15)
+
+
 @pytest.mark.parametrize("n", [16, 64, 256, 1024])
 def test_dn_corner_and_offdiag_formulas(oracle, n):
     D = oracle.dn(n)
@@ -60,6 +69,37 @@ def test_dn_against_independent_60_digit_evaluation(oracle, n):
     if n >= 3:
         Dinv, _ = oracle.integration(n)
         assert np.linalg.norm(Dinv - g[f"Dinv{n}"]) / np.linalg.norm(g[f"Dinv{n}"]) <= 1e-12
+
+
+def test_large_grids_against_independent_60_digit_evaluation(oracle):
+    """The sizes the metric is quoted on.  tests/golden/dn_exact_mp_large.npz (make_golden.py --large): exact-maths D_N and
+    Dn_NN^-1 at N=256 in full, and at N=1024 sixteen rows + the diagonal of D_N and twelve columns + rows of Dn_NN^-1
+    (iterative refinement in 60-digit arithmetic).  Gates = 2x what this host measures; SURVEY Appendix B predicts
+    7.2e-13 for the normwise forming error of D_256 (node rounding: one ulp in x moves near-diagonal entries by 5.9e-12)."""
+    g = np.load(os.path.join(GOLD, "dn_exact_mp_large.npz"))
+    fro = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert np.abs(oracle.points(256) - g["x256"]).max() <= 4e-16 and np.abs(oracle.points(1024) - g["x1024"]).max() <= 4e-16
+    assert fro(oracle.dn(256), g["D256"]) <= 1.5e-12                  # measured 7.18e-13
+    assert fro(oracle.integration(256)[0], g["Dinv256"]) <= 1e-13     # measured 2.1e-14
+    D = oracle.dn(1024)
+    assert fro(D[g["D1024_row_idx"]], g["D1024_rows"]) <= 2e-11       # measured 6.0e-12
+    assert fro(np.diag(D), g["D1024_diag"]) <= 3e-11                  # measured 7.4e-12
+    Dinv = oracle.integration(1024)[0]
+    idx = g["Dinv1024_idx"]
+    assert fro(Dinv[:, idx], g["Dinv1024_cols"]) <= 1e-12             # measured 1.9e-13
+    assert fro(Dinv[idx, :], g["Dinv1024_rows"]) <= 1e-12             # measured 1.0e-13
+
+
+def test_integration_matrix_1024_extended_precision_residual(oracle):
+    """Whole-matrix check at N=1024: Dn_NN . Dn_NN^-1 - I evaluated in 80-bit arithmetic.  Because ||Dn_NN^-1||_inf = 1
+    (checked below), the largest residual entry of a column bounds the forward error of every entry of that column."""
+    n = 1024
+    Dinv, _ = oracle.integration(n)
+    Dnn = oracle.dn(n)[:-1, :-1]
+    L = np.longdouble
+    R = Dnn.astype(L) @ Dinv.astype(L) - np.eye(n - 1, dtype=L)
+    assert float(np.abs(R).max()) <= 1e-11                            # measured 2.6e-13; cond_2 = 8.3e5
+    assert abs(np.abs(Dinv).sum(axis=1).max() - 1.0) <= 1e-11
 
 
 @pytest.mark.parametrize("n", [16, 64, 256])

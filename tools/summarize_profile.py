@@ -19,6 +19,15 @@ def find(sub, pat):
 
 
 summary = {"tag": tag}
+line = None
+try:
+    line = json.loads([ln for ln in open(os.path.join(out, "bench_line.json")) if ln.strip().startswith("{")][-1])
+    cfg = line["config"]
+    summary["workload"] = cfg["workload"]
+    summary["bench_unprofiled"] = {"kernel_ms": line["roofline"]["kernel_ms"], "ms_per_step": line["ms_per_step"],
+                                   "value": line["value"], "roofline": {k: line["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+except Exception as e:  # noqa: BLE001
+    summary["bench_line_error"] = str(e)
 f = find("trace", "*kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
@@ -65,9 +74,15 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles are summed over all SIMDs (1024)
     gui = sq["GRBM_GUI_ACTIVE"][0] / 8.0
     summary["mfma_busy_frac_of_active_cycles"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (gui * 1024.0)
+if "hbm_bytes_per_launch" in summary and line is not None:
+    import datetime
+    cfg = line["config"]
+    alg = line["roofline"]["algorithmic_bytes_per_launch"]
+    summary["hbm_bytes_over_algorithmic"] = summary["hbm_bytes_per_launch"] / alg
+    rec = {"n": cfg["N"], "rods": cfg["rods_per_gpu"], "operator": cfg["operator"],
+           "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
+           "date": datetime.date.today().isoformat(),
+           "source": f"profiles/{tag}_rocprofv3_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"}
+    json.dump(rec, open(os.path.join(prof, f"hbm_traffic_n{cfg['N']}_r{cfg['rods_per_gpu']}_{cfg['operator']}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(prof, f"{tag}_rocprofv3_summary.json"), "w"), indent=1)
-if "hbm_bytes_per_launch" in summary:
-    json.dump({"n": 256, "rods": 65536, "operator": "dn", "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-               "source": f"profiles/{tag}_rocprofv3_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"},
-              open(os.path.join(prof, "hbm_traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
