@@ -95,7 +95,8 @@ class SriError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_PKG, _LIB_NAME)
+    # SRI_HIP_LIBRARY: an alternative build of the SAME library (A/B measurements of kernel variants, tools/ only)
+    return os.environ.get("SRI_HIP_LIBRARY") or os.path.join(_PKG, _LIB_NAME)
 
 
 def build_library(force: bool = False) -> str:

@@ -23,9 +23,11 @@
 //   * The X fragment is the MFMA's first operand, i.e. every tile is accumulated TRANSPOSED: the 16
 //     lanes of a quarter-wave hold 16 rows of one column, and interleaving the rows of two stacked
 //     tiles (row_of_slot) gives each lane two adjacent rows, so Y leaves in 16-byte stores that
-//     are 256 contiguous bytes per quarter-wave.  k is consumed in the order (k pair j, lane
-//     k-slot g, element e) -> 8j + 2g + e.  Both permutations are folded into the host-side
-//     packing of A; X and Y keep the caller's plain column-major layout.
+//     are 256 contiguous bytes per quarter-wave.  k is consumed in ASCENDING order, the reference's own
+//     (main.cpp:172): MFMA (k pair j, element e) sums k = 8j + 4e + g over the lanes' k slots g, fed by 8-byte
+//     X-fragment reads (sri_internal.h: k_of_ascending; the 16-byte alternative sums equal-parity k's together
+//     and is measurably less accurate on smooth fields).  The row permutation and the k order are folded into the
+//     host-side packing of A; X and Y keep the caller's plain column-major layout.
 //   * PERSISTENT: one 512-thread workgroup per CU (256 x 128 tile, 2 waves per SIMD, 144 KiB LDS
 //     ring of 3 stages, 2 in flight) walks tiles b, b+grid, ...; the (tile, k chunk) pairs form one
 //     stream that keeps flowing across tile boundaries.  Stages are awaited with counted
@@ -46,8 +48,10 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails with an error.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -79,6 +83,11 @@ void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 constexpr int BK = kChunkK;          // 16 k per stage
 constexpr int KPAIRS = BK / 8;       // 16-byte fragment reads per stage and tile
 constexpr int X_ROW_BYTES = BK * 8;  // one column of the X stage: 128 B = 8 pieces of 16 B
+#ifndef SRI_ASCENDING_K
+#define SRI_ASCENDING_K 1            // 1: k consumed in the reference's ascending order (8-byte X-fragment reads); 0: paired
+#endif
+constexpr bool ASCK = SRI_ASCENDING_K != 0;
+inline constexpr int k_of(int j, int g, int e) { return ASCK ? k_of_ascending(j, g, e) : k_of_paired(j, g, e); }
 #ifndef SRI_SCHED_HINTS
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
 #endif
@@ -204,7 +213,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // groups ({0-3,12-15,20-27}, ...; tools/lds_bank_model.py): with the plain column order & 7 is conflict-free, with the
   // permuted column order of EPI_QUAT it is 2-way (measured: SQ_LDS_BANK_CONFLICT = 0.5 x the X-read cycles) and & 6 is
   // conflict-free instead.
-  constexpr int SWZ = EPI == EPI_QUAT ? 6 : 7;
+  // With the ascending k order the X fragments are 8-byte reads, served in two 32-lane halves that each cover all 16
+  // columns of the tile in either column order: & 7 is conflict-free for both.
+  constexpr int SWZ = (EPI == EPI_QUAT && !ASCK) ? 6 : 7;
   constexpr bool FOLD = RANK1 && (TAIL || !DMA);
   constexpr bool RANK1_EPI = RANK1 && !FOLD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -410,6 +421,17 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
   const int sig = (cs >> 1) & SWZ;
   const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
+  // Ascending k: one 8-byte X read per MFMA.  The per-tile offsets are kept opaque: seen as constants 2 KiB apart,
+  // hipcc pairs the reads of two tiles into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and,
+  // banked mod 32 over 128-byte rows, with 2-way conflicts (measured: -2 % at N = 256).
+  int xrd[ASCK ? TN : 1];
+  if constexpr (ASCK) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      xrd[tn] = x_off + tn * 16 * X_ROW_BYTES + (g & 1) * 8;
+      keep_live(xrd[tn]);
+    }
+  }
 
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
   // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
@@ -431,10 +453,20 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
       a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
-    const int xpiece = ((4 * j + g) ^ sig) * 16;
+    if constexpr (ASCK) {
+      // instruction (j, e) sums k = 8j + 4e + g over the lanes' k slots g: element g & 1 of piece 4j + 2e + (g >> 1)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-      b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+      for (int e = 0; e < 2; ++e) {
+        const int xoff = ((4 * j + 2 * e + (g >> 1)) ^ sig) * 16;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[tn][e] = *reinterpret_cast<const double*>(base + xrd[tn] + xoff);
+      }
+    } else {
+      const int xpiece = ((4 * j + g) ^ sig) * 16;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+    }
   };
   // groups [G0, G1) of the k pair held in (a, b); `piece` counts the DMA pieces issued so far in this body
   auto mfma_groups = [&](const d2 (&a)[TM], const d2 (&b)[TN], auto g0_tag, auto g1_tag, int& piece, auto pieces_tag)
@@ -952,16 +984,26 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
 // Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
 // that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
 // inside a stream capture (HIP graph).
+// Written under prepare()'s lock (handles may be created from several host threads, on the same or on different
+// devices), read lock-free by launch().
+constexpr int kMaxDevices = 16;
 template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
-static int& residency(int dev) {
-  static int blocks_per_cu[16] = {};
+static std::atomic<int>& residency(int dev) {
+  static std::atomic<int> blocks_per_cu[kMaxDevices] = {};
   return blocks_per_cu[dev];
+}
+
+static std::mutex& prepare_mutex() {
+  static std::mutex m;
+  return m;
 }
 
 template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
 static int prepare(int dev) {
-  if (dev < 0 || dev >= 16) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev) != 0) return SRI_OK;
+  if (dev < 0 || dev >= kMaxDevices) return SRI_EUNSUPPORTED;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
+  std::lock_guard<std::mutex> lock(prepare_mutex());
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
   const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>;
   constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
@@ -970,7 +1012,7 @@ static int prepare(int dev) {
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
-  residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev) = nb < 1 ? 1 : nb;
+  residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
   return SRI_OK;
 }
 
@@ -997,7 +1039,7 @@ static int prepare_geometry(int dev) {
 template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream,
                   uint32_t* partials = nullptr) {
-  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev);
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_acquire);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;

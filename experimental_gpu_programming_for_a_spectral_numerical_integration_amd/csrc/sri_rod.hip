@@ -311,6 +311,9 @@ struct sri_rod_handle {
   double* d_partial = nullptr;            // cap_partial: per-workgroup tip-update maxima of the fused step
   uint32_t cap_partial = 0;
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
+  // host side of that loop, owned by the handle (no per-call allocation, nothing to leak on an error return):
+  unsigned long long* h_state = nullptr;  // pinned, 2 slots x 4 words: the loop state read back per chunk
+  hipEvent_t done[2] = {nullptr, nullptr};
   sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64, (N-1) % 16 != 0), else null
   bool use_resident = true;
   bool emit_position_rhs = false;         // set by sri_rod_integrate: the confirmation pass also writes b = R(q) e1 into d_B
@@ -387,7 +390,10 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
       hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess ||
       (h->cap_partial = sri::max_partials(integ)) == 0 ||
       hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial) != hipSuccess ||
-      hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&h->done[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->done[1], hipEventDisableTiming) != hipSuccess) {
     sri_rod_destroy(h);
     return SRI_ENOMEM;
   }
@@ -456,6 +462,9 @@ int sri_rod_destroy(sri_rod_t* h) {
   if (h->d_diff) (void)hipFree(h->d_diff);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->d_state) (void)hipFree(h->d_state);
+  if (h->h_state) (void)hipHostFree(h->h_state);
+  for (hipEvent_t e : h->done)
+    if (e) (void)hipEventDestroy(e);
   delete h;
   return SRI_OK;
 }
@@ -598,12 +607,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
   const uint32_t kChunk = predicted ? 4u : 8u;                  // iterations enqueued per read-back of the loop state
   double* bufs[2] = {cur, nxt};                                 // iteration k reads bufs[k & 1], writes bufs[(k + 1) & 1]
-  unsigned long long* h_state = nullptr;                        // 2 slots x 4 words, pinned
-  ROD_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault));
-  hipEvent_t done[2];
-  ROD_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming));
-  ROD_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming));
-  auto cleanup = [&]() { (void)hipEventDestroy(done[0]); (void)hipEventDestroy(done[1]); (void)hipHostFree(h_state); };
+  unsigned long long* const h_state = h->h_state;               // 2 slots x 4 words, pinned; owned by the handle
+  hipEvent_t* const done = h->done;
   // tips of Q^0 (what iteration 0 compares with): q_init in every column, or what the predictor left there
   if (!predicted) {
     hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
@@ -677,7 +682,6 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     enqueued = it;
     ROD_HIP(hipMemsetAsync(h->d_state, 0, sizeof(unsigned long long), stream));     // stop = 0, count and update kept
   }
-  cleanup();
   if (rc != SRI_OK) return rc;
   if (iters_out) *iters_out = it;
   if (last_update_out) *last_update_out = upd;

@@ -363,7 +363,7 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out) {
         for (int l = 0; l < 64; ++l)
           for (int e = 0; e < 2; ++e, ++o) {
             const uint32_t row = tm * 16 + (l & 15);
-            const uint32_t k = kc * 16 + k_of(j, l >> 4, e);
+            const uint32_t k = kc * 16 + k_of_paired(j, l >> 4, e);
             if (row < m && k < m) packed[o] = A[row + static_cast<size_t>(k) * m];
             else if (row < m && k == m) packed[o] = -w[row];
           }

@@ -27,7 +27,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
-        for s in ("sri_oracle.c", "sri_oracle_mt.c", "Makefile")
+        for s in ("sri_oracle.c", "sri_oracle_mt.c", "sri_mfma_model.c", "Makefile")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libsri_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -59,6 +59,8 @@ class _Sig:
     sri_oracle_apply_dot = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz]
     sri_oracle_apply_mt = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz, i]
     sri_oracle_integrate = [u32, _dp, sz, _dp, _dp, sz, _dp, _dp, sz, sz]
+    sri_model_apply = [i, u32, u32, _dp, sz, _dp, sz, _dp, sz, sz]
+    sri_model_apply_exact = [u32, u32, _dp, sz, _dp, sz, _dp, sz, sz]
     sri_oracle_legendre_basis = [dbl, u32, _dp]
     sri_oracle_strain = [dbl, u32, u32, _dp, _dp]
     sri_oracle_integrate_quaternions = [u32, _dp, u32, u32, _dp, _dp]
@@ -150,6 +152,30 @@ def apply(A: np.ndarray, X: np.ndarray, *, dot: bool = False, threads: int = 1) 
         _chk(lib().sri_oracle_apply_mt(r, k, _p(A), r, _p(X), k, _p(Y), r, M, threads), "apply_mt")
     else:
         _chk(lib().sri_oracle_apply(r, k, _p(A), r, _p(X), k, _p(Y), r, M), "apply")
+    return Y
+
+
+MODEL_KERNEL, MODEL_KERNEL_DESC, MODEL_KERNEL_EXACT4, MODEL_KERNEL_PAIRWISE4, MODEL_ASCENDING_FMA, MODEL_ASCENDING_MULADD = range(6)
+
+
+def model_apply(A: np.ndarray, X: np.ndarray, mode: int = MODEL_KERNEL) -> np.ndarray:
+    """Y = A @ X in the summation order / rounding model `mode` of sri_mfma_model.c (all host cores)."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    r, k = A.shape
+    assert X.shape[0] == k
+    Y = _fmat(r, X.shape[1])
+    _chk(lib().sri_model_apply(mode, r, k, _p(A), r, _p(X), k, _p(Y), r, X.shape[1]), "model_apply")
+    return Y
+
+
+def apply_exact(A: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """Y = A @ X accumulated in binary128 and rounded once: the yardstick two fp64 summation orders are measured against."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    r, k = A.shape
+    Y = _fmat(r, X.shape[1])
+    _chk(lib().sri_model_apply_exact(r, k, _p(A), r, _p(X), k, _p(Y), r, X.shape[1]), "model_apply_exact")
     return Y
 
 

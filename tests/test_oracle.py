@@ -206,3 +206,36 @@ def test_error_codes(oracle):
     buf = (C.c_double * 4)()
     assert lib.sri_oracle_points(1, 1.0, buf) == -1
     assert lib.sri_oracle_dn(4, buf, 3) == -1
+
+
+def test_mfma_arithmetic_models(oracle):
+    """oracle/sri_mfma_model.c: the CPU models of the kernel's summation.  MODEL_ASCENDING_MULADD is the oracle's own
+    arithmetic bit for bit; the FMA models differ from it by rounding only; exact small-integer products agree in every
+    model; the binary128 yardstick is at least as close to every model as they are to each other."""
+    from conftest import rod_strain_panel
+
+    rng = np.random.default_rng(5)
+    for rows, M in [(16, 9), (100, 33), (255, 17), (256, 40)]:
+        A = uniform_panel(rows, rows, seed=rows)
+        X = uniform_panel(rows, M, seed=rows + 1)
+        Y = oracle.apply(A, X)
+        assert np.array_equal(oracle.model_apply(A, X, oracle.MODEL_ASCENDING_MULADD), Y)
+        Yx = oracle.apply_exact(A, X)
+        for mode in range(6):
+            Ym = oracle.model_apply(A, X, mode)
+            assert np.linalg.norm(Ym - Yx) <= 4 * rows * 2.0 ** -53 * np.linalg.norm(np.abs(A) @ np.abs(X))
+        Ai = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
+        Xi = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
+        for mode in range(6):
+            assert np.array_equal(oracle.model_apply(Ai, Xi, mode), Ai @ Xi)
+        assert np.array_equal(oracle.apply_exact(Ai, Xi), Ai @ Xi)
+    # the regime that decides the k order: smooth field under D_1024.  Equal-parity k's summed together (the 16-byte
+    # fragment order) is ~1.4x farther from the true product than the reference's arithmetic; ascending k with fused
+    # multiply-adds is closer than the reference itself.
+    n = 1024
+    A = oracle.dn(n)
+    X = rod_strain_panel(n, 16)
+    Yx = oracle.apply_exact(A, X)
+    err = {m: np.linalg.norm(oracle.model_apply(A, X, m) - Yx) / np.linalg.norm(Yx) for m in (0, 4, 5)}
+    assert err[oracle.MODEL_ASCENDING_FMA] < err[oracle.MODEL_ASCENDING_MULADD] < err[oracle.MODEL_KERNEL]
+    assert err[oracle.MODEL_ASCENDING_MULADD] <= 1.2e-12 and err[oracle.MODEL_ASCENDING_FMA] <= 0.8e-12

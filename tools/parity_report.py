@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Parity figures of the apply at the BASELINE sizes, for DESIGN.md §5 / profiles/ (run on the GPU box).
+
+For N in {64, 256, 1024}, the D_N apply at the full BASELINE batch, uniform and rod-strain panels: on a sample of
+columns, the Frobenius-relative distance of the GPU result and of the CPU oracle from a binary128 product, the distance
+GPU <-> oracle, the backward error, and whether the GPU result equals the ascending-k FMA model bit for bit.
+Writes one JSON object (stdout + gpurun_out/parity_report.json)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import oracle  # noqa: E402
+import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri  # noqa: E402
+
+out = {"columns_sampled": 2048, "rows": []}
+dev = torch.device("cuda", 0)
+for n, rods in ((64, 4096), (256, 65536), (1024, 8192)):
+    A = oracle.dn(n)
+    op = sri.SpectralApply(n, sri.OP_DN, device=0)
+    for kind in ("uniform", "rod"):
+        X = bench.device_panel(torch, n, n, rods, kind, 0x5EED, dev)
+        Y = op.apply(X)
+        M = 4 * rods
+        idx = torch.from_numpy(np.unique(np.random.default_rng(9).integers(0, M, size=out["columns_sampled"]))).cuda()
+        Xs = np.asfortranarray(X[idx].cpu().numpy().T)
+        Ys = np.asfortranarray(Y[idx].cpu().numpy().T)
+        Yo = oracle.apply(A, Xs, threads=0)
+        Yx = oracle.apply_exact(A, Xs)
+        Ym = oracle.model_apply(A, Xs, oracle.MODEL_ASCENDING_FMA)
+        f = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        scale = np.abs(A) @ np.abs(Xs)
+        row = {"N": n, "rods": rods, "panel": kind, "kernel": op.last_kernel,
+               "gpu_vs_oracle_fro": f(Ys, Yo), "gpu_vs_binary128_fro": f(Ys, Yx), "oracle_vs_binary128_fro": f(Yo, Yx),
+               "gpu_vs_oracle_max_rel": float(np.abs(Ys - Yo).max() / np.abs(Yo).max()),
+               "backward_error": float(np.max(np.abs(Ys - Yo) / scale)), "backward_bound_8N_u": 8.0 * n * 2.0 ** -53,
+               "bit_exact_vs_ascending_fma_model": bool(np.array_equal(Ys, Ym))}
+        out["rows"].append(row)
+        print(json.dumps(row), flush=True)
+        del X, Y
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w"), indent=1)
