@@ -50,6 +50,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -153,6 +154,20 @@ struct ApplyArgs {
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Y is written once and never read by the kernel: non-temporal stores keep it from lingering in L2, where it would be
+// flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.5 -> 8.1 us
+// at 8 192 rods, 204.8 -> 199.0 us at 262 144; N = 128: -6 %; N = 256 / 1024: +-0.2 %.
+#ifndef SRI_NT_STORES
+#define SRI_NT_STORES 1
+#endif
+__device__ __forceinline__ void store_y(d2* p, d2 v) {
+#if SRI_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
 }
 
 // Diagnostic builds: keep a register value opaque/live without emitting an instruction.  (The "v"
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
               v0 -= wv[t][0] * xbv;
               v1 -= wv[t][1] * xbv;
             }
-            if (all_rows || row + 1 < p.rows) *reinterpret_cast<d2*>(yp) = d2{v0, v1};   // 16 B, 8-byte aligned is fine
+            if (all_rows || row + 1 < p.rows) store_y(reinterpret_cast<d2*>(yp), d2{v0, v1});   // 16 B, 8-byte aligned is fine
             else *yp = v0;                                                             // the lane holding the last row
           }
         }
@@ -955,6 +970,7 @@ struct sri_apply_handle {
   int num_cus = 0;
   uint32_t max_workgroups = 0;   // 0 = fill the chip; else cap of the persistent grid (leave CUs to a collective)
   double* d_apack = nullptr;
+  double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   const char* last_kernel = "none";
 };
@@ -1169,10 +1185,25 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   }
   auto fail = [&](int code) {
     if (h->d_apack) (void)hipFree(h->d_apack);
+    if (h->d_apack_small) (void)hipFree(h->d_apack_small);
     if (h->d_w) (void)hipFree(h->d_w);
     delete h;
     return code;
   };
+  // SRI_APPLY_NO_SMALL=1 (diagnostics, A/B timing): keep 64-row operators on the general kernel
+  const char* no_small = std::getenv("SRI_APPLY_NO_SMALL");
+  if (small_supported(rows) && !(no_small && no_small[0] == '1')) {
+    rc = small_prepare(device);
+    if (rc != SRI_OK) return fail(rc);
+    std::vector<double> sp;
+    try {
+      small_pack(A, lda, sp);
+    } catch (const std::bad_alloc&) {
+      return fail(SRI_ENOMEM);
+    }
+    if (hipMalloc(&h->d_apack_small, sp.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+    if (hipMemcpy(h->d_apack_small, sp.data(), sp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+  }
   if (hipMalloc(&h->d_apack, packed.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
   if (hipMemcpy(h->d_apack, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
     return fail(SRI_EHIP);
@@ -1198,6 +1229,11 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   DeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
+
+  if (h->d_apack_small != nullptr && !rank1 && quat == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
+    h->last_kernel = "sri_apply_mfma_f64<64x64,dma,one-tile-per-workgroup>";
+    return small_launch(h->d_apack_small, dX, ldx, dY, ldy, M, d_tips, h->device, h->num_cus, h->max_workgroups, stream);
+  }
 
   ApplyArgs args;
   args.apack = h->d_apack;
@@ -1373,6 +1409,7 @@ int sri_apply_destroy(sri_apply_t* h) {
   sri::DeviceGuard guard;
   (void)guard.enter(h->device);
   if (h->d_apack) (void)hipFree(h->d_apack);
+  if (h->d_apack_small) (void)hipFree(h->d_apack_small);
   if (h->d_w) (void)hipFree(h->d_w);
   delete h;
   return SRI_OK;

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "sri_capi.h"
 
@@ -42,6 +43,15 @@ int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const doub
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials = nullptr);
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
+
+// ---- the latency kernel for 64-row operators and small batches: one tile per workgroup (sri_apply_small.hip) ---------
+constexpr uint32_t kSmallRows = 64;
+bool small_supported(uint32_t rows);
+bool small_batch(size_t M, int num_cus, uint32_t max_wgs);                // M columns fit one resident round of tiles
+void small_pack(const double* A, size_t lda, std::vector<double>& out);   // rows x rows column-major -> fragment order
+int small_prepare(int dev);                                               // `dev` must be current
+int small_launch(const double* d_apack, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, double* d_tips, int dev,
+                 int num_cus, uint32_t max_wgs, void* stream);
 
 // ---- on-chip rod pipeline for small grids (sri_rod_resident.hip, used by sri_rod.hip) -----------------------------
 struct ResidentRod;

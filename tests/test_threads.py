@@ -13,7 +13,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 def build_tsan(out_dir):
     lib = os.path.join(out_dir, "libsri_hip_tsan.so")
-    srcs = ["sri_host.cpp", "sri_apply.hip", "sri_rod.hip", "sri_rod_resident.hip", "sri_comm.hip"]
+    srcs = ["sri_host.cpp", "sri_apply.hip", "sri_apply_small.hip", "sri_rod.hip", "sri_rod_resident.hip", "sri_comm.hip"]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off",
                            "-fsanitize=thread", "-Wno-option-ignored", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                            "-I", "/opt/rocm/include", "-shared", "-o", lib, "-x", "hip", *[os.path.join(CSRC, s) for s in srcs],

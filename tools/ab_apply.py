@@ -2,6 +2,7 @@
 """A/B timing of two builds of libsri_hip.so in ONE process, interleaved rounds (cdna_hip_programming.md §5.4 rule 24).
 
     python tools/ab_apply.py --n 256 --rods 65536 --libs A=path/to/a.so B=path/to/b.so [--rounds 5] [--reps 200]
+    python tools/ab_apply.py --n 64 --rods 4096 --libs small=lib.so general=lib.so,SRI_APPLY_NO_SMALL=1
 
 Prints min / median kernel time per variant (HIP events around `reps` back-to-back launches) and the TF/s."""
 import argparse
@@ -34,6 +35,12 @@ def main():
     variants = []
     for spec in a.libs:
         name, path = spec.split("=", 1)
+        envs = []
+        if "," in path:                                        # name=path,ENV=VAL,...: environment seen by sri_apply_create
+            path, *envs = path.split(",")
+        for kv in envs:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
         lib = C.CDLL(os.path.abspath(path))
         lib.sri_apply_create.argtypes = [C.POINTER(vp), u32, i32, i32]
         lib.sri_apply.argtypes = [vp, vp, sz, vp, sz, sz, vp]
@@ -41,6 +48,8 @@ def main():
         h = vp()
         rc = lib.sri_apply_create(C.byref(h), a.n, a.operator, 0)
         assert rc == 0, rc
+        for kv in envs:
+            os.environ.pop(kv.split("=", 1)[0], None)
         r = u32()
         lib.sri_apply_dim(h, C.byref(r))
         variants.append((name, lib, h, r.value))
