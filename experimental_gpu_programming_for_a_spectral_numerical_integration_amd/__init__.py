@@ -73,6 +73,7 @@ C_ABI = {
     "sri_last_rccl_error": (_int, []),
     "sri_rccl_strerror": (C.c_char_p, [_int]),
     "sri_apply_last_kernel": (C.c_char_p, [_vp]),
+    "sri_apply_summation_order": (_int, [_vp, C.POINTER(_int)]),
     "sri_strerror": (C.c_char_p, [_int]),
     "sri_last_hip_error": (_int, []),
     "sri_abi_version": (_int, []),
@@ -307,6 +308,13 @@ class SpectralApply:
     @property
     def last_kernel(self) -> str:
         return load_library().sri_apply_last_kernel(self._h).decode()
+
+    @property
+    def ascending_k(self) -> bool:
+        """True if launches sum k = 0, 1, 2, ... like main.cpp:172; False: evens before odds inside blocks of 8 k."""
+        a = _int()
+        _chk(load_library().sri_apply_summation_order(self._h, C.byref(a)), "sri_apply_summation_order")
+        return bool(a.value)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

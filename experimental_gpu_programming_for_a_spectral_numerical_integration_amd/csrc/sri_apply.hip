@@ -84,11 +84,17 @@ void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 constexpr int BK = kChunkK;          // 16 k per stage
 constexpr int KPAIRS = BK / 8;       // 16-byte fragment reads per stage and tile
 constexpr int X_ROW_BYTES = BK * 8;  // one column of the X stage: 128 B = 8 pieces of 16 B
-#ifndef SRI_ASCENDING_K
-#define SRI_ASCENDING_K 1            // 1: k consumed in the reference's ascending order (8-byte X-fragment reads); 0: paired
-#endif
-constexpr bool ASCK = SRI_ASCENDING_K != 0;
-inline constexpr int k_of(int j, int g, int e) { return ASCK ? k_of_ascending(j, g, e) : k_of_paired(j, g, e); }
+// The k order of a launch (template parameter ASC of the kernel, fixed per handle; sri_internal.h has the two maps):
+//   paired    (rows <= 512): a lane's 16-byte X read holds two consecutive k, so an MFMA sums four k of equal parity —
+//             fewest LDS instructions (measured 2.4 % faster at N = 256 than ascending);
+//   ascending (rows  > 512): the reference's own order, from 8-byte X reads (one per MFMA).  On smooth fields under
+//             D_1024 the paired order is 1.56e-12 away from the CPU reference (1.33e-12 from a binary128 product), the
+//             ascending order 0.97e-12 (0.55e-12; the CPU reference itself: 0.92e-12) — profiles/r02_parity_report.json.
+// Both orders are reproduced bit for bit by a CPU model in the test tree (a chain of four fused multiply-adds per MFMA).
+// Measured and dropped: ascending order from 16-byte reads + v_permlane16_swap_b32 (two 32-bit VALU moves per fragment
+// exchange the halves between adjacent 16-lane rows): correct, but 2.1 % slower than the 8-byte reads.
+constexpr uint32_t kAscendingAboveRows = 512;
+inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_ascending(j, g, e) : k_of_paired(j, g, e); }
 #ifndef SRI_SCHED_HINTS
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
 #endif
@@ -218,8 +224,9 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 // ---------------------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_QUAT = 1 };
 
-template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE>
+template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
+  constexpr bool ASCK = ASC;
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
   const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
-  const int sig = (cs >> 1) & SWZ;
+  const int sig = ((cs >> 1) & SWZ);
   const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
   // Ascending k: one 8-byte X read per MFMA.  The per-tile offsets are kept opaque: seen as constants 2 KiB apart,
   // hipcc pairs the reads of two tiles into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and,
@@ -972,6 +979,7 @@ struct sri_apply_handle {
   double* d_apack = nullptr;
   double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
+  bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
   const char* last_kernel = "none";
 };
 
@@ -980,7 +988,7 @@ namespace sri {
 // `w` (optional, rows % 16 != 0 only): the rank-1 factor, packed negated as operator column k = rows — the free slot of
 // the last k chunk; the kernel puts x_base[col] (or 0 for a plain apply) into the matching slot of the X image.
 template <class G>
-static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t nk, uint32_t row_blocks, const double* w,
+static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                           std::vector<double>& out) {
   out.assign(static_cast<size_t>(row_blocks) * nk * G::BM * BK, 0.0);
   size_t o = 0;
@@ -991,7 +999,7 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
           for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 2; ++e, ++o) {
               const uint32_t row = rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15);
-              const uint32_t k = kc * BK + k_of(j, l >> 4, e);
+              const uint32_t k = kc * BK + k_of(asc, j, l >> 4, e);
               if (row < rows && k < rows) out[o] = A[row + static_cast<size_t>(k) * lda];
               else if (w != nullptr && row < rows && k == rows) out[o] = -w[row];
             }
@@ -1003,7 +1011,7 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
 // Written under prepare()'s lock (handles may be created from several host threads, on the same or on different
 // devices), read lock-free by launch().
 constexpr int kMaxDevices = 16;
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
 static std::atomic<int>& residency(int dev) {
   static std::atomic<int> blocks_per_cu[kMaxDevices] = {};
   return blocks_per_cu[dev];
@@ -1014,13 +1022,13 @@ static std::mutex& prepare_mutex() {
   return m;
 }
 
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
 static int prepare(int dev) {
   if (dev < 0 || dev >= kMaxDevices) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
   std::lock_guard<std::mutex> lock(prepare_mutex());
-  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
-  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
+  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>;
   constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
   // the attribute is the most any launch of this kernel may ask for
@@ -1028,7 +1036,7 @@ static int prepare(int dev) {
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
-  residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
+  residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
   return SRI_OK;
 }
 
@@ -1040,6 +1048,10 @@ static int prepare_geometry(int dev) {
   if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
+  if constexpr (G::BM > 128) {                                  // ascending k order: only operators with rows > 512
+    if (rc == SRI_OK) rc = prepare<G, true, false, false, EPI_NONE, 0, true>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true>(dev);
+  }
   if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
   if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
   if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
@@ -1052,10 +1064,10 @@ static int prepare_geometry(int dev) {
 
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream,
                   uint32_t* partials = nullptr) {
-  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS>(dev).load(std::memory_order_acquire);
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_acquire);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks;
   if (tiles == 0) return SRI_OK;
@@ -1070,7 +1082,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     *partials = grid * G::WN;
   }
   constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI>), dim3(grid), dim3(G::THREADS), lds, stream, args);
+  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>), dim3(grid), dim3(G::THREADS), lds, stream, args);
   SRI_HIP(hipGetLastError());
   return SRI_OK;
 }
@@ -1078,6 +1090,13 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
 template <class G>
 static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
+  if constexpr (G::BM > 128) {
+    if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
+      if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;
+      return args.tail_k != 0 ? launch<G, true, false, true, EPI_NONE, 0, true>(args, col_tiles, h->device, h->num_cus, h->max_workgroups, stream)
+                              : launch<G, true, false, false, EPI_NONE, 0, true>(args, col_tiles, h->device, h->num_cus, h->max_workgroups, stream);
+    }
+  }
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0;
@@ -1163,6 +1182,10 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->rows = rows;
   h->which = which;
   h->geo = rows <= 64 ? GEO_FLAT : (rows <= 128 ? GEO_MID : GEO_TALL);
+  // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
+  // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
+  // and fused-step variants are built on) keeps the faster paired order at every size.
+  h->ascending = rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
   h->bm = h->geo == GEO_FLAT ? GeoFlat::BM : (h->geo == GEO_MID ? GeoMid::BM : GeoTall::BM);
   h->nk = (rows + BK - 1) / BK;
   h->row_blocks = (rows + h->bm - 1) / h->bm;
@@ -1176,9 +1199,9 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   std::vector<double> packed;
   try {
     const double* wf = (rows % BK != 0) ? w_host : nullptr;
-    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
-    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
-    else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, wf, packed);
+    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, wf, false, packed);
+    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, false, packed);
+    else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
   } catch (const std::bad_alloc&) {
     delete h;
     return SRI_ENOMEM;
@@ -1416,6 +1439,12 @@ int sri_apply_destroy(sri_apply_t* h) {
 }
 
 const char* sri_apply_last_kernel(const sri_apply_t* h) { return h ? h->last_kernel : "none"; }
+
+int sri_apply_summation_order(const sri_apply_t* h, int* ascending) {
+  if (h == nullptr || ascending == nullptr) return SRI_EINVAL;
+  *ascending = h->ascending ? 1 : 0;
+  return SRI_OK;
+}
 
 int sri_last_hip_error(void) { return sri::g_last_hip_error; }
 

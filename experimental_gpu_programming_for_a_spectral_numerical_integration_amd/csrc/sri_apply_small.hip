@@ -19,8 +19,9 @@
 //     then drain under the second pass's MFMAs;
 //   * Y leaves in NON-TEMPORAL 16-byte stores: written once, never read here, and lines that linger in L2 are flushed at
 //     the end of the kernel (6.1 -> 5.4 us per launch);
-//   * arithmetic: v_mfma_f64_16x16x4_f64 only, k consumed in ascending order (sri_internal.h: k_of_ascending), tile
-//     accumulated transposed so that Y leaves in 16-byte stores — the same bits as the general kernel produces.
+//   * arithmetic: v_mfma_f64_16x16x4_f64 only, k consumed in the paired order of the general kernel for this size
+//     (sri_internal.h: k_of_paired), tile accumulated transposed so that Y leaves in 16-byte stores — the same bits as
+//     the general kernel produces, whichever of the two a batch size selects.
 // Result: 5.4 us per back-to-back launch instead of 6.3 (2.9 of them the launch floor).  Batches with more tiles than
 // resident workgroups (2 per CU) stay on the general kernel, whose k-chunk ring streams at the device's copy rate.
 //
@@ -73,11 +74,6 @@ __device__ __forceinline__ void barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void opaque_s(int& v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+s"(v));
-#endif
-}
 template <class T>
 __device__ __forceinline__ void opaque(T& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -125,21 +121,11 @@ __global__ __launch_bounds__(THREADS, 2) void apply_small_kernel(const Args p) {
     }
   };
 
-  // ---- fragment reads: lane (c, g) feeds X[column 16 tn + c of the wave][k = 4s + g] to MFMA s of the chunk.  The chunk
-  // and column-tile offsets are kept opaque: seen as constants 2 / 8 KiB apart, hipcc pairs two reads into
-  // ds_read2st64_b64 (half the LDS rate and, banked mod 32 over 128-byte rows, 2-way conflicts).
+  // ---- fragment reads, the paired k order of the general kernel for operators of this size (sri_internal.h:
+  // k_of_paired): lane (c, g) reads the 16 bytes X[column 16 tn + c of the wave][k = 8j + 2g, 8j + 2g + 1] of k pair j and
+  // feeds element e to MFMA (j, e).  The results are the same bits whichever kernel a batch size selects.
   const int sig = (c >> 1) & 7;
-  int xrd[2], off[CHUNKS];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    xrd[tn] = (wc * 32 + tn * 16 + c) * 128 + (g & 1) * 8;
-    opaque(xrd[tn]);
-  }
-#pragma unroll
-  for (int kc = 0; kc < CHUNKS; ++kc) {
-    off[kc] = kc * CHUNK_BYTES;
-    opaque_s(off[kc]);
-  }
+  const int xrd = (wc * 32 + c) * 128;
   d2 a[2][KPAIRS];                                  // the operator: 16 fragment pairs per lane
   d4 acc[2][2];
   auto read_a = [&](int kc) __attribute__((always_inline)) {
@@ -149,38 +135,36 @@ __global__ __launch_bounds__(THREADS, 2) void apply_small_kernel(const Args p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) a[tm][kc * 2 + j] = *reinterpret_cast<const d2*>(base + (tm * 2 + j) * 1024);
   };
-  // the four k-steps of chunk KC (step s = 4 k's: pair s >> 1, element s & 1) for the column tiles in MASK; the fragments
-  // of step s + 1 are read before the MFMAs of step s are issued
-  auto read_x = [&](const char* chunk, int s, double (&b)[2], int mask) __attribute__((always_inline)) {
-    const int xoff = ((4 * (s >> 1) + 2 * (s & 1) + (g >> 1)) ^ sig) * 16;
+  // the two k pairs of chunk KC for the column tiles in MASK; the fragments of pair 1 are read before the MFMAs of pair 0
+  auto read_x = [&](const char* chunk, int j, d2 (&b)[2], int mask) __attribute__((always_inline)) {
+    const int xoff = ((4 * j + g) ^ sig) * 16;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
-      if (mask & (1 << tn)) b[tn] = *reinterpret_cast<const double*>(chunk + xrd[tn] + xoff);
+      if (mask & (1 << tn)) b[tn] = *reinterpret_cast<const d2*>(chunk + xrd + tn * 2048 + xoff);
   };
   auto compute_chunk = [&](auto kc_tag, auto mask_tag) __attribute__((always_inline)) {
     constexpr int KC = decltype(kc_tag)::value, MASK = decltype(mask_tag)::value;
-    const char* chunk = smem + off[KC];
-    double b[2][2];
+    const char* chunk = smem + KC * CHUNK_BYTES;
+    d2 b[2][2];
     read_x(chunk, 0, b[0], MASK);
+    if constexpr ((ABL & 8) == 0) read_x(chunk, 1, b[1], MASK);
+    else { b[1][0] = b[0][0]; b[1][1] = b[0][1]; }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int cur = s & 1;
-      if (s + 1 < 4) {
-        if constexpr ((ABL & 8) == 0) read_x(chunk, s + 1, b[cur ^ 1], MASK);
-        else { b[cur ^ 1][0] = b[cur][0]; b[cur ^ 1][1] = b[cur][1]; }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if constexpr ((ABL & 1) == 0) {
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              if (MASK & (1 << tn))
+                acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j][tn][e], a[tm][KC * 2 + j][e], acc[tm][tn], 0, 0, 0);
+        } else {
+          opaque(b[j][0]);
+          opaque(b[j][1]);
+        }
       }
-      if constexpr ((ABL & 1) == 0) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            if (MASK & (1 << tn))
-              acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[cur][tn], a[tm][KC * 2 + (s >> 1)][s & 1], acc[tm][tn], 0, 0, 0);
-      } else {
-        opaque(b[cur][0]);
-        opaque(b[cur][1]);
-      }
-    }
   };
   using std::integral_constant;
 
@@ -265,7 +249,7 @@ void small_pack(const double* A, size_t lda, std::vector<double>& out) {
           for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 2; ++e, ++o) {
               const int row = 32 * wr + row_of_slot(tm, l & 15);
-              const int k = 16 * kc + k_of_ascending(j, l >> 4, e);
+              const int k = 16 * kc + k_of_paired(j, l >> 4, e);
               out[o] = A[row + static_cast<size_t>(k) * lda];
             }
 }

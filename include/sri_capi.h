@@ -254,6 +254,13 @@ const char *sri_rccl_strerror(int rccl_result);
  * (static string, e.g. "sri_apply_mfma_f64<256x64,dma>"). */
 const char *sri_apply_last_kernel(const sri_apply_t *h);
 
+/* The order in which a launch of this handle sums the products of one output element (see csrc/sri_internal.h):
+ * *ascending = 1: k = 0, 1, 2, ... as main.cpp:172 does (operators of more than 512 rows other than Dn_NN^-1);
+ * *ascending = 0: inside every block of 8 consecutive k, the even ones before the odd ones.  Either way every
+ * multiply-add is fused (v_mfma_f64_16x16x4_f64 is a chain of four FMAs), and the result is a fixed function of the
+ * inputs: no atomics, no run-to-run variation, the same bits for every batch size and device. */
+int sri_apply_summation_order(const sri_apply_t *h, int *ascending);
+
 const char *sri_strerror(int status);
 int sri_last_hip_error(void);
 int sri_abi_version(void);

@@ -80,12 +80,13 @@ def backward_tol(n: int) -> float:   # 8 N 2^-53
     return 8.0 * n * 2.0 ** -53
 
 
-def assert_apply_parity(oracle, A, X, Y, n, what=""):
+def assert_apply_parity(oracle, A, X, Y, n, what="", ascending=None):
     """The parity gate of the apply, in decreasing strength:
 
-    1. bit for bit equal to the CPU model of the kernel's arithmetic (oracle/sri_mfma_model.c, MODEL_ASCENDING_FMA): every
-       output element is the reference's own loop (main.cpp:172: k = 0, 1, 2, ... ascending) with each multiply-add fused
-       — v_mfma_f64_16x16x4_f64 is a chain of four FMAs over its k slots;
+    1. bit for bit equal to the CPU model of the kernel's arithmetic (oracle/sri_mfma_model.c): every output element is
+       a chain of fused multiply-adds — v_mfma_f64_16x16x4_f64 is four FMAs over its k slots — over k in the order the
+       handle reports (sri_apply_summation_order): the reference's own ascending order (main.cpp:172) for differentiation
+       operators of more than 512 rows, else evens before odds inside every block of 8 k;
     2. against the CPU oracle (multiply, then add: two roundings per term) <= 1e-12 in the Frobenius norm and
        <= 8 N 2^-53 in the backward error max |E| / (|A||X|);
     3. where the oracle ITSELF is not within 1e-12 of the true product — the smooth rod field under D_1024
@@ -95,9 +96,12 @@ def assert_apply_parity(oracle, A, X, Y, n, what=""):
     Returns the measured figures."""
     Yref = oracle.apply(A, X, threads=0)
     fro, back = parity_metrics(A, X, Y, Yref)
-    bit_exact = bool(np.array_equal(Y, oracle.model_apply(A, X, oracle.MODEL_ASCENDING_FMA)))
-    out = {"fro_vs_oracle": fro, "backward": back, "bit_exact_vs_fma_model": bit_exact}
-    assert bit_exact, (what, "differs from the ascending-k FMA model", fro)
+    if ascending is None:
+        ascending = A.shape[0] > 512
+    model = oracle.MODEL_ASCENDING_FMA if ascending else oracle.MODEL_KERNEL
+    bit_exact = bool(np.array_equal(Y, oracle.model_apply(A, X, model)))
+    out = {"fro_vs_oracle": fro, "backward": back, "bit_exact_vs_fma_model": bit_exact, "ascending_k": bool(ascending)}
+    assert bit_exact, (what, "differs from the FMA-chain model", "ascending" if ascending else "paired", fro)
     assert back <= backward_tol(n), (what, back)
     if fro > FRO_TOL:
         Yx = oracle.apply_exact(A, X)

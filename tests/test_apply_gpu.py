@@ -65,7 +65,8 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
     op = sri.SpectralApply(n, which)
     assert op.rows == rows
     Y = _run(op, X)
-    assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, kind, op.last_kernel))
+    assert op.ascending_k == (rows > 512 and which != 1)
+    assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, kind, op.last_kernel), ascending=op.ascending_k)
     expect_dma = rows >= 16          # every panel of >= 16 rows takes the LDS-DMA build, whatever its alignment
     assert ("dma" in op.last_kernel) == expect_dma, op.last_kernel
 
@@ -177,7 +178,7 @@ def test_integrate_matches_oracle(sri, oracle, n):
     fro, back = parity_metrics(Dinv, rhs, Y, Yref)
     assert fro <= FRO_TOL, fro
     # the initial-value term rides in the product as one more k (operator column -w = -Dinv Din, X row x_base):
-    # bit for bit the ascending-k FMA chain over the extended operands
+    # bit for bit the FMA chain over the extended operands
     w = np.zeros(n - 1)
     for k in range(n - 1):
         w = w + Dinv[:, k] * Din[k]
@@ -185,7 +186,8 @@ def test_integrate_matches_oracle(sri, oracle, n):
     Xext = np.asfortranarray(np.concatenate([B, xb[None, :]], axis=0))
     lib = oracle.lib()
     Ym = np.zeros((n - 1, M), order="F")
-    assert lib.sri_model_apply(oracle.MODEL_ASCENDING_FMA, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
+    assert not op.ascending_k                        # the integration operator keeps the paired order at every size
+    assert lib.sri_model_apply(oracle.MODEL_KERNEL, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
                                Xext.ctypes.data_as(oracle._dp), n, Ym.ctypes.data_as(oracle._dp), n - 1, M) == 0
     assert np.array_equal(Y, Ym)
     # backward error is measured against |Dinv| (|B| + |Din||xb|): the epilogue form reassociates the rank-1 term

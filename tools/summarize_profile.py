@@ -10,12 +10,16 @@ out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
-KERNEL = "apply_kernel"
+KERNELS = ("apply_kernel", "apply_small_kernel")
+
+
+def is_apply(name):
+    return any(k in name for k in KERNELS)
 
 
 def find(sub, pat):
     hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 summary = {"tag": tag}
@@ -37,7 +41,7 @@ if f:
         for r in rows:
             w.writerow([r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
     for r in rows:
-        if KERNEL in r["Name"]:
+        if is_apply(r["Name"]):
             summary["kernel"] = r["Name"][:140]
             summary["calls"] = int(r["Calls"])
             summary["avg_ns"] = float(r["AverageNs"])
@@ -50,7 +54,7 @@ def pmc(sub):
     if not f:
         return acc
     for r in csv.DictReader(open(f)):
-        if KERNEL not in r.get("Kernel_Name", ""):
+        if not is_apply(r.get("Kernel_Name", "")):
             continue
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
