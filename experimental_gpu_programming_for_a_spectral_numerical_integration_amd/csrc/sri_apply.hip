@@ -154,6 +154,7 @@ struct ApplyArgs {
   uint32_t row_blocks;
   uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
   uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
+  uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
 };
 
@@ -164,16 +165,16 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
 
 // Y is written once and never read by the kernel: non-temporal stores keep it from lingering in L2, where it would be
 // flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.5 -> 8.1 us
-// at 8 192 rods, 204.8 -> 199.0 us at 262 144; N = 128: -6 %; N = 256 / 1024: +-0.2 %.
+// at 8 192 rods, 204.8 -> 199.0 us at 262 144; N = 128: -6 %; N = 256 / 1024: +-0.2 %.  Only for panels whose columns start
+// on 128-byte lines (ApplyArgs::nt_stores, set by run()): on a 255-row panel with leading dimension 255 a quarter-wave's
+// 256 bytes straddle three lines and written-through partial lines cost 3 % instead (0.544 vs 0.527 ms at N = 256).
 #ifndef SRI_NT_STORES
 #define SRI_NT_STORES 1
 #endif
+template <bool NT>
 __device__ __forceinline__ void store_y(d2* p, d2 v) {
-#if SRI_NT_STORES
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+  if constexpr (NT && SRI_NT_STORES != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 // Diagnostic builds: keep a register value opaque/live without emitting an instruction.  (The "v"
@@ -641,26 +642,30 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           wv[t][1] = p.w[row_base + 32 * t + 1];   // w is zero padded
         }
       }
+      auto emit = [&](auto nt_tag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(nt_tag)::value;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const size_t col = col_base + tn * 16 + r * 4;
-          double xbv = 0.0;
-          if constexpr (RANK1_EPI) xbv = p.xb[col];
+          for (int r = 0; r < 4; ++r) {
+            const size_t col = col_base + tn * 16 + r * 4;
+            double xbv = 0.0;
+            if constexpr (RANK1_EPI) xbv = p.xb[col];
 #pragma unroll
-          for (int t = 0; t < TM / 2; ++t) {
-            const uint32_t row = row_base + 32 * t;
-            double* yp = p.y + col * p.ldy + row;
-            double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
-            if constexpr (RANK1_EPI) {
-              v0 -= wv[t][0] * xbv;
-              v1 -= wv[t][1] * xbv;
+            for (int t = 0; t < TM / 2; ++t) {
+              const uint32_t row = row_base + 32 * t;
+              double* yp = p.y + col * p.ldy + row;
+              double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
+              if constexpr (RANK1_EPI) {
+                v0 -= wv[t][0] * xbv;
+                v1 -= wv[t][1] * xbv;
+              }
+              if (all_rows || row + 1 < p.rows) store_y<NT>(reinterpret_cast<d2*>(yp), d2{v0, v1});   // 16 B, 8-byte aligned is fine
+              else *yp = v0;                                                                 // the lane holding the last row
             }
-            if (all_rows || row + 1 < p.rows) store_y(reinterpret_cast<d2*>(yp), d2{v0, v1});   // 16 B, 8-byte aligned is fine
-            else *yp = v0;                                                             // the lane holding the last row
           }
-        }
+      };
+      if (p.nt_stores != 0) emit(std::true_type{}); else emit(std::false_type{});   // same store count either way
       emit_tips(rb_c, col_base);
       return true;
     } else {
@@ -1288,6 +1293,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // the register-staged build.
   const bool dma = h->rows >= 16;
   args.tail_k = h->rows % 16;
+  args.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
   h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);

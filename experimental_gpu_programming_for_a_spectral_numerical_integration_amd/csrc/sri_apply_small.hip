@@ -17,8 +17,8 @@
 //     register load beside an LDS-DMA in flight with s_waitcnt vmcnt(0).)
 //   * each wave takes its 32 columns in TWO passes of 16: the first while the chunks are still arriving, and its stores
 //     then drain under the second pass's MFMAs;
-//   * Y leaves in NON-TEMPORAL 16-byte stores: written once, never read here, and lines that linger in L2 are flushed at
-//     the end of the kernel (6.1 -> 5.4 us per launch);
+//   * Y leaves in NON-TEMPORAL 16-byte stores (when its columns start on 128-byte lines): written once, never read
+//     here, and lines that linger in L2 are flushed at the end of the kernel (6.1 -> 5.4 us per launch);
 //   * arithmetic: v_mfma_f64_16x16x4_f64 only, k consumed in the paired order of the general kernel for this size
 //     (sri_internal.h: k_of_paired), tile accumulated transposed so that Y leaves in 16-byte stores — the same bits as
 //     the general kernel produces, whichever of the two a batch size selects.
@@ -59,6 +59,7 @@ struct Args {
   double* tips;          // optional: tips[col] = Y[0][col]
   size_t ldx, ldy, m;
   uint32_t tiles;        // == gridDim.x
+  uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores
 };
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(THREADS, 2) void apply_small_kernel(const Args p) {
           opaque(acc[1][tn]);
         } else if (full || col < p.m) {
           d2* yp = reinterpret_cast<d2*>(p.y + col * p.ldy + row);    // 16 B at 8-byte alignment is fine
-          if constexpr ((ABL & 16) != 0) *yp = d2{acc[0][tn][r], acc[1][tn][r]};
+          if ((ABL & 16) != 0 || p.nt_stores == 0) *yp = d2{acc[0][tn][r], acc[1][tn][r]};
           else __builtin_nontemporal_store(d2{acc[0][tn][r], acc[1][tn][r]}, yp);
           if (p.tips != nullptr && wr == 0 && c == 0) p.tips[col] = acc[0][tn][r];
         }
@@ -281,7 +282,8 @@ int small_launch(const double* d_apack, const double* dX, size_t ldx, double* dY
   const size_t tiles = (M + BN - 1) / BN;
   if (tiles == 0) return SRI_OK;
   if (!small_batch(M, num_cus, max_wgs)) return SRI_EUNSUPPORTED;
-  Args args{d_apack, dX, dY, d_tips, ldx, ldy, M, static_cast<uint32_t>(tiles)};
+  Args args{d_apack, dX, dY, d_tips, ldx, ldy, M, static_cast<uint32_t>(tiles),
+            (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u};
   const unsigned grid = static_cast<unsigned>(tiles);                 // one tile per workgroup
   hipLaunchKernelGGL(apply_small_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, static_cast<hipStream_t>(stream), args);
   hipError_t e = hipGetLastError();

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   const size_t tiles = (M + BN - 1) / BN;
   if (tiles > (size_t)prop.multiProcessorCount * 2) { printf("one tile per workgroup: at most %d rods\n", prop.multiProcessorCount * 2 * 16); return 1; }
   const unsigned grid = (unsigned)tiles;
-  Args a{dA, dX, dY, nullptr, n, n, M, (uint32_t)tiles};
+  Args a{dA, dX, dY, nullptr, n, n, M, (uint32_t)tiles, 1u};
   const double bytes = 16.0 * n * M + 8.0 * n * n, flops = 2.0 * n * n * M;
   printf("N=64 rods=%zu tiles=%zu grid=%u  algorithmic %.2f MB / %.3f GFLOP per launch; HBM floor at 6.29 TB/s %.2f us, MFMA floor %.2f us\n", rods, tiles, grid,
          bytes / 1e6, flops / 1e9, bytes / 6.29e6, flops / 78.6e6);
