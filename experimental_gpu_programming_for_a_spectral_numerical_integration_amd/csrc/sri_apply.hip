@@ -716,6 +716,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool STAGGER = (NW >= 8) && (SRI_SCHED_HINTS != 0);
   const bool late = STAGGER && wid >= NW / 2;
 
+#if defined(SRI_PRIO_LATE)
+  if (late) __builtin_amdgcn_s_setprio(SRI_PRIO_LATE);
+#endif
+#if defined(SRI_PRIO_EARLY)
+  if (STAGGER && !late) __builtin_amdgcn_s_setprio(SRI_PRIO_EARLY);
+#endif
   issue_setup();
   for (int i = 0; i < AHEAD; ++i) {
     if (issued < total_stages) {
