@@ -164,8 +164,8 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
 }
 
 // Y is written once and never read by the kernel: non-temporal stores keep it from lingering in L2, where it would be
-// flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.5 -> 8.1 us
-// at 8 192 rods, 204.8 -> 199.0 us at 262 144; N = 128: -6 %; N = 256 / 1024: +-0.2 %.  Only for panels whose columns start
+// flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.4 -> 8.0 us
+// at 8 192 rods, 200.7 -> 197.3 us at 262 144; N = 128: -7 %; N = 256 / 1024: -0.1 %.  Only for panels whose columns start
 // on 128-byte lines (ApplyArgs::nt_stores, set by run()): on a 255-row panel with leading dimension 255 a quarter-wave's
 // 256 bytes straddle three lines and written-through partial lines cost 3 % instead (0.544 vs 0.527 ms at N = 256).
 #ifndef SRI_NT_STORES
@@ -716,12 +716,6 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool STAGGER = (NW >= 8) && (SRI_SCHED_HINTS != 0);
   const bool late = STAGGER && wid >= NW / 2;
 
-#if defined(SRI_PRIO_LATE)
-  if (late) __builtin_amdgcn_s_setprio(SRI_PRIO_LATE);
-#endif
-#if defined(SRI_PRIO_EARLY)
-  if (STAGGER && !late) __builtin_amdgcn_s_setprio(SRI_PRIO_EARLY);
-#endif
   issue_setup();
   for (int i = 0; i < AHEAD; ++i) {
     if (issued < total_stages) {
