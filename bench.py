@@ -240,6 +240,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     comm_box = [None]                                       # the C ABI's RCCL communicator (created below)
+    comm_hung = False
 
     def all_gather(out, inp):
         if rehearsal:
@@ -277,13 +278,27 @@ def main():
     elif use_dist and args.collective == "torch":
         collective = "torch.distributed (RCCL)"
     elif use_dist:
+        import threading
         from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel
-        err = ""
-        try:
-            comm_box[0] = parallel.Communicator.from_torch_distributed(local_rank)
-        except Exception as e:                              # noqa: BLE001 — reported in the result line
-            err = str(e)
-        okf = torch.tensor([1.0 if comm_box[0] is not None else 0.0], dtype=torch.float64, device=dev)
+        err_box = [""]
+        box = [parallel.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+
+        def create():                                       # ncclCommInitRank is collective: never wait on it forever
+            try:
+                torch.cuda.set_device(local_rank)
+                comm_box[0] = parallel.Communicator(box[0], rank, world, local_rank)
+            except Exception as e:                          # noqa: BLE001 — reported in the result line
+                err_box[0] = str(e)
+
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("SRI_COMM_TIMEOUT_S", "120")))
+        if th.is_alive():
+            err_box[0] = "sri_comm_create did not return in time"
+            comm_hung = True
+        err = err_box[0]
+        okf = torch.tensor([1.0 if (comm_box[0] is not None and not comm_hung) else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)
         if okf.item() == 1.0:
             collective = "sri_comm (libsri_hip.so: RCCL from C++)"
@@ -511,6 +526,11 @@ def main():
 
     if use_dist:
         dist.barrier()
+        if comm_hung:                                       # a thread is stuck inside RCCL: leave without joining it
+            sys.stdout.flush()
+            os._exit(0)
+        if comm_box[0] is not None:
+            comm_box[0].close()
         dist.destroy_process_group()
 
 

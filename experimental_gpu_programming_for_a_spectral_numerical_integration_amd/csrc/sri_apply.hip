@@ -162,6 +162,8 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// (A non-temporal / sc0 cache policy on the X-panel pieces — read once, so that they would not evict the operator from
+// L2 — was measured at N = 1024, where the operator is re-streamed 2.6 x: 0.4-0.8 % slower; N = 256: no change.)
 
 // Y is written once and never read by the kernel: non-temporal stores keep it from lingering in L2, where it would be
 // flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.4 -> 8.0 us
