@@ -65,6 +65,28 @@ int fail(ncclResult_t e) {
   return SRI_ECOMM;
 }
 
+// Makes `device` current for the scope of a call and restores the caller's device afterwards.
+struct CommDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  int enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != device) {
+      e = hipSetDevice(device);
+      switched = e == hipSuccess;
+    }
+    if (e != hipSuccess) {
+      sri::record_hip_error(static_cast<int>(e));
+      (void)hipGetLastError();
+      return SRI_EHIP;
+    }
+    return SRI_OK;
+  }
+  ~CommDeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 }  // namespace
 
 struct sri_comm_handle {
@@ -98,11 +120,9 @@ int sri_comm_create(sri_comm_t** out, const void* id, int rank, int world, int d
   }
   const Rccl& r = rccl();
   if (!r.ok) return SRI_EUNSUPPORTED;
-  he = hipSetDevice(device);
-  if (he != hipSuccess) {
-    sri::record_hip_error(static_cast<int>(he));
-    return SRI_EHIP;
-  }
+  CommDeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SRI_OK) return rc;
   sri_comm_handle* h = new (std::nothrow) sri_comm_handle;
   if (!h) return SRI_ENOMEM;
   h->rank = rank;
@@ -122,6 +142,8 @@ int sri_comm_create(sri_comm_t** out, const void* id, int rank, int world, int d
 int sri_comm_destroy(sri_comm_t* h) {
   if (!h) return SRI_OK;
   int rc = SRI_OK;
+  CommDeviceGuard guard;
+  (void)guard.enter(h->device);
   if (h->comm) {
     ncclResult_t e = rccl().CommDestroy(h->comm);
     if (e != ncclSuccess) rc = fail(e);
@@ -143,6 +165,9 @@ int sri_comm_rank(const sri_comm_t* h, int* rank, int* world) {
 static int allgather_doubles(sri_comm_t* h, const double* d_local, size_t count_local, double* d_all, const size_t* counts,
                              void* stream) {
   if (!h || !h->comm || !d_all || (!d_local && count_local)) return SRI_EINVAL;
+  CommDeviceGuard guard;
+  int grc = guard.enter(h->device);
+  if (grc != SRI_OK) return grc;
   const Rccl& r = rccl();
   hipStream_t s = static_cast<hipStream_t>(stream);
   bool equal = true;

@@ -44,3 +44,9 @@ def test_header_has_the_reference_signatures():
                 "getDn()"):
         assert sig in text
     assert "#ifndef CHEBYSHEV_DIFFERENTIATION_H" in text            # same include guard as the reference header
+
+
+def test_cpp_multi_gpu_example_compiles(sri, tmp_path):
+    """The C++-only multi-GPU example builds against the C ABI (run on the GPU box by tests/test_examples_gpu.py)."""
+    _build(str(tmp_path), os.path.join(ROOT, "examples", "multi_gpu_gather.cpp"), "multi_gpu_gather",
+           extra=("-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-pthread", "-Werror"))

@@ -48,3 +48,14 @@ def test_rod_main_config1_matches_oracle(sri, oracle, tmp_path):
     outb = subprocess.run([exe, "100", "--full"], capture_output=True, text=True, check=True).stdout
     Qb, rb = _parse(outb)
     assert np.abs(rb - ro).max() <= 1e-13 and "sri_apply_mfma_f64" in outb
+
+
+@pytest.mark.parametrize("force_ragged", ["0", "1"])
+def test_multi_gpu_gather_from_cpp(sri, tmp_path, force_ragged):
+    """examples/multi_gpu_gather.cpp: the sharded apply + RCCL all-gather of the tip state from C++ only (host threads, one
+    per GPU; the box has one, so the communicator has one rank — the same ncclCommInitRank / all-gather calls)."""
+    exe = _build(str(tmp_path), os.path.join(ROOT, "examples", "multi_gpu_gather.cpp"), "multi_gpu_gather",
+                 extra=("-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"))
+    env = dict(os.environ, SRI_COMM_FORCE_RAGGED=force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "1", "1003"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "verified" in r.stdout, (r.stdout, r.stderr[-2000:])

@@ -42,7 +42,42 @@ def check(BK, sigma, ncol_tiles=4):
     return res
 
 
+# ---- round 2: the ascending k order reads X with ds_read_b64 (one k per lane and MFMA) ---------------------------------
+# ds_read_b64 is serviced in two 32-lane halves over 64 banks of 4 B (256-byte bank row): conflict-free iff the 32 lanes
+# touch 32 distinct 8-byte slots.  ds_read2_b64 / ds_read2st64_b64 (what hipcc makes of two such reads whose addresses
+# differ by a constant) are banked mod 32 (128-byte row) in four contiguous 16-lane groups.
+def worst_way_b64(addr_of_lane, banks_bytes=256, groups=(range(0, 32), range(32, 64))):
+    worst = 1
+    for grp in groups:
+        slots = {}
+        for l in grp:
+            slots.setdefault((addr_of_lane(l) % banks_bytes) // 8, set()).add(addr_of_lane(l))
+        worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+
+
+def check_ascending(sigma, read2=False):
+    res = set()
+    for tn in range(4):
+        for j in range(2):
+            for e in range(2):
+                def addr(l, tn=tn, j=j, e=e):
+                    c = tn * 16 + (l & 15)
+                    g = l >> 4
+                    p = 4 * j + 2 * e + (g >> 1)                 # k = 8j + 4e + g lives in piece p, element g & 1
+                    return c * 128 + ((p ^ sigma(c)) % 8) * 16 + (g & 1) * 8
+                if read2:
+                    res.add(worst_way_b64(addr, 128, (range(0, 16), range(16, 32), range(32, 48), range(48, 64))))
+                else:
+                    res.add(worst_way_b64(addr))
+    return sorted(res)
+
+
 if __name__ == "__main__":
+    print("ascending k, ds_read_b64,  sigma=(c>>1)&7 :", check_ascending(lambda c: (c >> 1) & 7))
+    print("ascending k, ds_read_b64,  sigma=none     :", check_ascending(lambda c: 0))
+    print("ascending k, ds_read2[st64]_b64 (banked mod 32), sigma=(c>>1)&7 :", check_ascending(lambda c: (c >> 1) & 7, read2=True),
+          "<- why the reads are kept apart")
     for BK, name, sig in [
         (16, "none", lambda c: 0),
         (16, "(c>>1)&7", lambda c: (c >> 1) & 7),
