@@ -12,7 +12,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # measurement tooling (not product code); binaries land in build/ (git-ignored, travels with gpurun)
-tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe
+tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe build/small_diag build/stream_probe
 
 build/mfma_f64_probe: tools/mfma_f64_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -include algorithm $< -o $@
@@ -20,8 +20,14 @@ build/mfma_f64_probe: tools/mfma_f64_probe.hip
 build/store_rate_probe: tools/store_rate_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
-build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
-	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Wno-pass-failed tools/apply_diag.hip $(PKG)/csrc/sri_host.cpp -o $@
+build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Wno-pass-failed tools/apply_diag.hip $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host.cpp -o $@
+
+build/small_diag: tools/small_diag.hip $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_internal.h
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) tools/small_diag.hip -o $@
+
+build/stream_probe: tools/stream_probe.hip
+	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
 
 clean:
 	$(MAKE) -C $(PKG)/csrc clean; $(MAKE) -C oracle clean; rm -rf build
