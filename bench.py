@@ -125,6 +125,25 @@ def _stats(ts):
     return ts[0], ts[len(ts) // 2]
 
 
+def usable_cores() -> int:
+    """Host threads this process may actually run on: the smaller of the affinity mask and the cgroup CPU quota (a GPU box
+    hands one job a share of its cores; 128 OpenMP threads on a 16-core share only measure the scheduler)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                       # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                                                    # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(n: int, budget_s: float, data: str):
     """Oracle (kind "port") on a bounded sample of the same workload: single thread like the
     reference's main.cpp, then all host cores; >= 3 repetitions each, min and median."""
@@ -142,14 +161,14 @@ def cpu_baseline(n: int, budget_s: float, data: str):
     t1 = []
     for _ in range(reps):
         t0 = time.perf_counter(); oracle.apply(A, X); t1.append(time.perf_counter() - t0)
-    threads = oracle.max_threads()
+    threads = min(oracle.max_threads(), usable_cores())
     # all cores: a sample `threads/2` times larger so that a repetition is not shorter than the fork/join noise
     rods_mt = int(min(rods * max(threads // 2, 1), 65536, (512 << 20) // (32 * n)))
     Xm = host_panel(n, rods_mt, data, 0x5EED)
-    oracle.apply(A, Xm, threads=0)                        # warm the thread pool
+    oracle.apply(A, Xm, threads=threads)                  # warm the thread pool
     tm = []
     for _ in range(reps):
-        t0 = time.perf_counter(); oracle.apply(A, Xm, threads=0); tm.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); oracle.apply(A, Xm, threads=threads); tm.append(time.perf_counter() - t0)
     b1, m1 = _stats(t1)
     bm, mm = _stats(tm)
     return {
@@ -158,7 +177,8 @@ def cpu_baseline(n: int, budget_s: float, data: str):
                   f"min of {reps} (median in median_value)",
         "median_value": rods / m1, "reps": reps,
         "all_cores_value": rods_mt / bm, "all_cores_median_value": rods_mt / mm, "all_cores": threads,
-        "all_cores_sample": f"{rods_mt} rods, OpenMP over column blocks, min of {reps}",
+        "all_cores_sample": f"{rods_mt} rods, OpenMP over column blocks on {threads} threads (affinity mask / cgroup quota; "
+                            f"the host reports {os.cpu_count()} logical CPUs), min of {reps}",
     }
 
 
