@@ -391,3 +391,46 @@ def test_randomised_shape_sweep_against_the_oracle_product(sri, oracle):
         rel = np.linalg.norm(Y - ref) / np.linalg.norm(ref)
         assert rel <= 1e-12, (case, rows, M, ldx, ldy, rel)
         assert torch.isnan(Yp[:, rows:]).all()                    # the padding between columns is never written
+
+
+def test_small_batch_kernel_matches_the_general_kernel_bit_for_bit(sri, monkeypatch):
+    """64-row operators: batches of at most one tile per resident workgroup take the one-tile kernel (sri_apply_small.hip),
+    larger ones the general kernel.  Same arithmetic, same k order: the bits must not depend on which one ran."""
+    import torch
+
+    op = sri.SpectralApply(64, 0)
+    monkeypatch.setenv("SRI_APPLY_NO_SMALL", "1")
+    general = sri.SpectralApply(64, 0)                      # the switch is read when the handle is created
+    monkeypatch.delenv("SRI_APPLY_NO_SMALL")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M in (1, 63, 64, 65, 4097, 16384, 32768, 32769, 100000):
+        X = torch.rand((M, 64), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+        tips_a = torch.empty(M, dtype=torch.float64, device="cuda")
+        tips_b = torch.empty(M, dtype=torch.float64, device="cuda")
+        Ya, Yb = op.apply(X, tips=tips_a), general.apply(X, tips=tips_b)
+        torch.cuda.synchronize()
+        assert ("one-tile" in op.last_kernel) == (M <= 32768), (M, op.last_kernel)
+        assert "one-tile" not in general.last_kernel
+        assert torch.equal(Ya, Yb) and torch.equal(tips_a, tips_b) and torch.equal(tips_a, Ya[:, 0].contiguous()), M
+
+
+def test_small_batch_kernel_is_graph_capturable(sri):
+    import torch
+
+    op = sri.SpectralApply(64, 0)
+    X = torch.rand((16384, 64), dtype=torch.float64, device="cuda") * 2 - 1
+    Y = torch.zeros_like(X)
+    ref = op.apply(X)
+    torch.cuda.synchronize()
+    assert "one-tile" in op.last_kernel
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(8):
+                op.apply(X, out=Y)
+    Y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Y, ref)
