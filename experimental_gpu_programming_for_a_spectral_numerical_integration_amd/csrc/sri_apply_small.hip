@@ -99,7 +99,7 @@ __global__ __launch_bounds__(THREADS, 2) void apply_small_kernel(const Args p) {
 
   // ---- k chunk kc of the tile's panel -> LDS.  A chunk is 8 one-KiB pieces, piece q = columns 8q .. 8q+7 x 128 B; wave w
   // moves pieces w and w + 4.  Lane: column 8q + (lane >> 3), image piece lane & 7 <- source piece (lane & 7) ^
-  // sigma(column), sigma = (column >> 1) & 7 (conflict-free 8-byte fragment reads, as in sri_apply.hip).
+  // sigma(column), sigma = (column >> 1) & 7 (conflict-free 16-byte fragment reads, as in sri_apply.hip).
   auto issue_x = [&](int kc) __attribute__((always_inline)) {
     const size_t col0 = static_cast<size_t>(tile) * BN;
     char* dst = smem + kc * CHUNK_BYTES;
