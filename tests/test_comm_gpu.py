@@ -52,3 +52,36 @@ def test_one_rank_communicator(force_ragged):
     env = dict(os.environ, SRI_COMM_FORCE_RAGGED=force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "COMM_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+TWO_RANKS_ONE_DEVICE = r"""
+import os, sys, threading, time
+sys.path.insert(0, {root!r})
+import torch
+from experimental_gpu_programming_for_a_spectral_numerical_integration_amd import parallel, SriError
+torch.cuda.set_device(0)
+uid = parallel.Communicator.unique_id()
+res = {{}}
+def mk(r):
+    try:
+        parallel.Communicator(uid, r, 2, 0)
+        res[r] = "created"
+    except SriError as e:
+        res[r] = e.status
+ts = [threading.Thread(target=mk, args=(r,), daemon=True) for r in range(2)]
+[t.start() for t in ts]
+[t.join(60) for t in ts]
+print("RESULT", res.get(0), res.get(1), [t.is_alive() for t in ts], flush=True)
+os._exit(0)
+"""
+
+
+def test_two_ranks_rendezvous_and_fail_cleanly_on_one_device():
+    """A two-rank communicator through the C ABI on the one-GPU box: both ranks find each other through the 128-byte token
+    (the bootstrap of a real multi-GPU job), then RCCL refuses two ranks on one device — as SRI_ECOMM on BOTH ranks, within
+    seconds, never a hang."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", TWO_RANKS_ONE_DEVICE.format(root=ROOT)], capture_output=True, text=True, timeout=300, env=env)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, (r.stdout[-1000:], r.stderr[-2000:])
+    assert line[0] == "RESULT -8 -8 [False, False]", line[0]
