@@ -296,10 +296,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
         xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
         // In the last k chunk of a panel whose row count is not a multiple of 16, a piece that holds a k
-        // beyond the last row must not be fetched from where it "would be" (that is the next column, or past
-        // the end of the buffer): it is fetched from the same piece of the PREVIOUS chunk instead (a full chunk
-        // of the same column: rows >= 17 here) and its LDS image is rewritten by fixup_tail() before use.
-        if constexpr (TAIL) xsafe[it] = (2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
+        // beyond the last row reaches into the next column — or, for the panel's last column, past the end of the
+        // buffer: THAT one is fetched from the same piece of the PREVIOUS chunk instead (a full chunk of the same
+        // column: rows >= 17 here) and its LDS image is rewritten by fixup_tail() before use.
+        // Only the LAST column of the panel needs that: behind every other column lies the next one (or the padding of a
+        // strided panel), so the piece can be fetched where it is — its valid element arrives by DMA like any other and
+        // fixup_tail() only overwrites the foreign one.
+        if constexpr (TAIL) xsafe[it] = (col0_i + cc >= last_col && 2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -752,8 +755,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     for (uint32_t idx = tid; idx < G::BN * fixn; idx += G::THREADS) {
       const uint32_t cc = idx / fixn, kk = k0 + idx % fixn;
       const size_t col = col0_s + cc;
+      const bool valid = kbase + kk < p.rows;                // a real element of the column (only in the straddling piece)
+      if (valid && col < last_col) continue;                 // delivered by the DMA from its own address
       double v = 0.0;
-      if (col < p.m && kbase + kk < p.rows) v = p.x[col * p.ldx + kbase + kk];
+      if (valid && col == last_col) v = p.x[col * p.ldx + kbase + kk];   // the last column's pieces came from a safe address
       if constexpr (FOLD) { if (col < p.m && kbase + kk == p.rows) v = p.xb[col]; }
       const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & SWZ);
       *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;

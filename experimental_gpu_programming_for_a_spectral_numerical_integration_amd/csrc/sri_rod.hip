@@ -300,6 +300,8 @@ __global__ void picard_control_kernel(const double* __restrict__ partial, uint32
 struct sri_rod_handle {
   int device = 0;
   uint32_t n = 0, m = 0;
+  size_t ldw = 0;                        // leading dimension of the INTERNAL panels: m rounded up to 16 rows, so that their
+                                         // columns start on 128-byte lines (LDS-DMA and 16-byte stores at full rate; 1.5 %)
   sri_apply_t* integ = nullptr;          // Dn_NN^-1 with the rank-1 initial-value epilogue
   double* d_nodes = nullptr;             // x_0 .. x_{n-1}, host libm cos (chebyshev_differentiation.h:26)
   double* d_leg = nullptr;               // P1 of utilities.h:54-59 (= 2X - 1) at the unknown nodes, zero padded to the row blocks
@@ -329,7 +331,7 @@ static int ensure_workspace(sri_rod_handle* h, size_t rods) {
   auto rel = [&](double*& p) { if (p) (void)hipFree(p); p = nullptr; };
   rel(h->d_K); rel(h->d_G); rel(h->d_Qa); rel(h->d_B); rel(h->d_xb4); rel(h->d_xb3); rel(h->d_tips);
   h->cap_rods = 0;
-  const size_t m = h->m;
+  const size_t m = h->ldw;
   if (hipMalloc(&h->d_K, sizeof(double) * m * 3 * rods) != hipSuccess) return SRI_ENOMEM;
   if (hipMalloc(&h->d_G, sizeof(double) * m * 4 * rods) != hipSuccess) return SRI_ENOMEM;
   if (hipMalloc(&h->d_Qa, sizeof(double) * m * 4 * rods) != hipSuccess) return SRI_ENOMEM;
@@ -377,6 +379,7 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   h->device = device;
   h->n = n;
   h->m = n - 1;
+  h->ldw = (static_cast<size_t>(n - 1) + 15) & ~static_cast<size_t>(15);
   h->integ = integ;
   std::vector<double> x(n);
   sri::cheb_points(n, 1.0, x.data());
@@ -557,7 +560,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
                      qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4);
   ROD_HIP(hipGetLastError());
-  double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = m)
+  const size_t ldw = h->ldw;
+  double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = ldw)
   double* nxt = h->d_Qa;
   // Start of the fixed point.  With the predictor (N > 64): solve the same rods on a 32-node grid with the on-chip
   // pipeline (a fraction of one fine iteration), interpolate to the fine nodes, G^0 = 1/2 A(K) Q^0 — the fine loop then
@@ -576,7 +580,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
       const dim3 grid(static_cast<unsigned>((rods + sri::kProlongRods - 1) / sri::kProlongRods), (m + 255) / 256);
       hipLaunchKernelGGL(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
-                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, static_cast<size_t>(m), h->d_tips + cols);
+                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, ldw, h->d_tips + cols);
       ROD_HIP(hipGetLastError());
       predicted = true;
     } else if (rcc != SRI_OK && rcc != SRI_ENOTCONVERGED) {
@@ -585,12 +589,12 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   }
   if (!predicted) {
     // Q^0 = q_init at every node (in the caller's panel), G^0 = 1/2 A(K) Q^0
-    rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, m, stream);
+    rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, ldw, stream);
     if (rc != SRI_OK) return rc;
     hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
                        qi[0], qi[1], qi[2], qi[3], dQ, ldq, static_cast<double*>(nullptr));
     ROD_HIP(hipGetLastError());
-    rc = sri_rod_quaternion_rhs(h, h->d_K, m, dQ, ldq, rods, cur, m, stream);
+    rc = sri_rod_quaternion_rhs(h, h->d_K, ldw, dQ, ldq, rods, cur, ldw, stream);
     if (rc != SRI_OK) return rc;
   }
 
@@ -629,7 +633,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       epi.partial = h->d_partial;
       epi.stop = h->d_state;
       uint32_t partials = h->cap_partial;
-      int r = sri::integrate_quat_step(h->integ, bufs[k & 1], m, h->d_xb4, epi, bufs[(k + 1) & 1], m, cols,
+      int r = sri::integrate_quat_step(h->integ, bufs[k & 1], ldw, h->d_xb4, epi, bufs[(k + 1) & 1], ldw, cols,
                                        h->d_tips + (k & 1) * cols, stream, &partials);
       if (r != SRI_OK) return r;
       hipLaunchKernelGGL(sri::picard_control_kernel, dim3(1), dim3(256), 0, stream, h->d_partial, partials, tip_tol,
@@ -646,12 +650,11 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   auto finish = [&]() -> int {
     cur = bufs[it & 1];
     nxt = bufs[(it + 1) & 1];
-    int r = sri_integrate(h->integ, cur, m, h->d_xb4, dQ, ldq, cols, stream);
+    int r = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
     if (r != SRI_OK) return r;
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
-                       static_cast<size_t>(m), h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr),
-                       static_cast<size_t>(m));
+                       ldw, h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw);
     ROD_HIP(hipGetLastError());
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipStreamSynchronize(stream));
@@ -698,16 +701,15 @@ int sri_rod_integrate_positions(sri_rod_t* h, const double* dQ, size_t ldq, size
   rc = sri::ensure_workspace(h, rods);
   if (rc != SRI_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const uint32_t m = h->m;
   const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
   const double* ri = r_init ? r_init : r0;
   const size_t cols = 3 * rods;
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 3u,
                      ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
   ROD_HIP(hipGetLastError());
-  rc = sri_rod_position_rhs(h, dQ, ldq, rods, h->d_B, m, stream);
+  rc = sri_rod_position_rhs(h, dQ, ldq, rods, h->d_B, h->ldw, stream);
   if (rc != SRI_OK) return rc;
-  return sri_integrate(h->integ, h->d_B, m, h->d_xb3, dR, ldr, cols, stream);            // main.cpp:172
+  return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
 }
 
 int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
@@ -743,7 +745,7 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
   hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
                      cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
   ROD_HIP(hipGetLastError());
-  return sri_integrate(h->integ, h->d_B, h->m, h->d_xb3, dR, ldr, cols, stream);            // main.cpp:172
+  return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
 }
 
 }  // extern "C"
