@@ -12,7 +12,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # measurement tooling (not product code); binaries land in build/ (git-ignored, travels with gpurun)
-tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe build/small_diag build/stream_probe
+tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe build/small_diag build/stream_probe build/host_transfer_probe
 
 build/mfma_f64_probe: tools/mfma_f64_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -include algorithm $< -o $@
@@ -28,6 +28,9 @@ build/small_diag: tools/small_diag.hip $(PKG)/csrc/sri_apply_small.hip $(PKG)/cs
 
 build/stream_probe: tools/stream_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
+
+build/host_transfer_probe: tools/host_transfer_probe.hip
+	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -pthread $< -o $@
 
 clean:
 	$(MAKE) -C $(PKG)/csrc clean; $(MAKE) -C oracle clean; rm -rf build

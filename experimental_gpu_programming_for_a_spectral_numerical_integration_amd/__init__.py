@@ -292,13 +292,47 @@ class SpectralApply:
         return Y
 
     # -- host convenience (PCIe-inclusive) -------------------------------------------------------
-    def apply_host(self, X: np.ndarray) -> np.ndarray:
-        """``Y = A @ X`` for a column-major host matrix ``rows x M`` (staged through the GPU)."""
-        X = np.asfortranarray(X, dtype=np.float64)
-        if X.shape[0] != self.rows:
-            raise ValueError(f"X has {X.shape[0]} rows, operator has {self.rows}")
-        Y = _fmat(*X.shape)
-        _chk(load_library().sri_apply_host(self._h, _p(X), self.rows, _p(Y), self.rows, X.shape[1]), "sri_apply_host")
+    @staticmethod
+    def _host_panel(a, rows: int, what: str):
+        """(array, leading dimension, columns) of a column-major host panel: a Fortran-ordered matrix or a column slice of one."""
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 2 and a.shape[0] == rows):
+            raise ValueError(f"{what} must be a float64 matrix with {rows} rows")
+        if a.size == 0:
+            return a, rows, a.shape[1]
+        if a.shape[1] > 1 and (a.strides[0] != 8 or a.strides[1] % 8 or a.strides[1] < 8 * rows):
+            raise ValueError(f"{what} must be column-major (a Fortran-ordered matrix, or the leading rows of one)")
+        if a.shape[1] <= 1 and a.shape[0] > 1 and a.strides[0] != 8:
+            raise ValueError(f"{what} must be column-major")
+        ld = a.strides[1] // 8 if a.shape[1] > 1 else rows
+        return a, ld, a.shape[1]
+
+    def apply_host(self, X: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """``Y = A @ X`` for a column-major host matrix ``rows x M``; X and ``out`` may be the leading rows of a taller
+        Fortran-ordered matrix (leading dimension > rows).  The panel crosses PCIe in blocks while the previous block is
+        applied and the one before returns (``sri_apply_host``)."""
+        if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.strides[0] == 8):
+            X = np.asfortranarray(X, dtype=np.float64)
+        X, ldx, M = self._host_panel(X, self.rows, "X")
+        Y = np.empty((self.rows, M), dtype=np.float64, order="F") if out is None else out
+        Y, ldy, My = self._host_panel(Y, self.rows, "out")
+        if My != M:
+            raise ValueError("out must have as many columns as X")
+        _chk(load_library().sri_apply_host(self._h, _p(X), ldx, _p(Y), ldy, M), "sri_apply_host")
+        return Y
+
+    def integrate_host(self, B: np.ndarray, x_base: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host-panel form of :meth:`integrate` (``sri_integrate_host``): ``Dn_NN⁻¹·B − (Dn_NN⁻¹·Dn_IN)·x_baseᵀ``."""
+        if not (isinstance(B, np.ndarray) and B.dtype == np.float64 and B.ndim == 2 and B.strides[0] == 8):
+            B = np.asfortranarray(B, dtype=np.float64)
+        B, ldb, M = self._host_panel(B, self.rows, "B")
+        xb = np.ascontiguousarray(x_base, dtype=np.float64)
+        if xb.shape != (M,):
+            raise ValueError("x_base must hold one value per column")
+        Y = np.empty((self.rows, M), dtype=np.float64, order="F") if out is None else out
+        Y, ldy, My = self._host_panel(Y, self.rows, "out")
+        if My != M:
+            raise ValueError("out must have as many columns as B")
+        _chk(load_library().sri_integrate_host(self._h, _p(B), ldb, _p(xb), _p(Y), ldy, M), "sri_integrate_host")
         return Y
 
     def set_max_workgroups(self, n: int) -> None:

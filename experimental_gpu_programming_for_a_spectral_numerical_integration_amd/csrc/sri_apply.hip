@@ -48,6 +48,7 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails with an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -984,6 +985,8 @@ enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2 };
 
 }  // namespace sri
 
+namespace sri { struct HostPipe; }
+
 struct sri_apply_handle {
   int device = 0;
   uint32_t rows = 0;
@@ -997,6 +1000,7 @@ struct sri_apply_handle {
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
   const char* last_kernel = "none";
+  sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events and device slots, built on first use
 };
 
 namespace sri {
@@ -1098,8 +1102,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     *partials = grid * G::WN;
   }
   constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
-  hipLaunchKernelGGL((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>), dim3(grid), dim3(G::THREADS), lds, stream, args);
-  SRI_HIP(hipGetLastError());
+  SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>), dim3(grid), dim3(G::THREADS), lds, stream, args));
   return SRI_OK;
 }
 
@@ -1405,43 +1408,196 @@ int sri_integrate(sri_apply_t* h, const double* dB, size_t ldb, const double* d_
   return sri::run(h, dB, ldb, dY, ldy, M, d_x_base, static_cast<hipStream_t>(hip_stream));
 }
 
+}  // extern "C"
+
+namespace sri {
+
+// ---------------------------------------------------------------------------------------------
+// Host panels (sri_apply_host / sri_integrate_host — what the drop-in header calls).
+// The panel crosses PCIe in blocks of columns through a ring of device slots; three streams carry block b+1 to the card,
+// apply block b and bring block b-1 back at the same time, so a call costs about ONE direction of the link (both
+// directions run at once: 48 GB/s each way measured, tools/host_transfer_probe.hip) instead of in + apply + out.
+// The caller's buffers are page-locked for the duration of the call (hipHostRegister; a range the caller registered
+// itself is left alone) so that the copies really are asynchronous; if that fails the same stream program runs on
+// pageable memory, where HIP makes each copy block the host — slower, same result.
+// ---------------------------------------------------------------------------------------------
+struct HostPipe {
+  static constexpr int SLOTS = 3;
+  hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+  hipEvent_t landed[SLOTS] = {}, applied[SLOTS] = {}, returned[SLOTS] = {};
+  double* dX[SLOTS] = {};
+  double* dY[SLOTS] = {};
+  double* dB = nullptr;
+  size_t slot_doubles = 0, base_doubles = 0;
+
+  int reserve(size_t doubles_per_slot, size_t base) {
+    if (s_in == nullptr) {
+      SRI_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+      SRI_HIP(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking));
+      SRI_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+      for (int i = 0; i < SLOTS; ++i) {
+        SRI_HIP(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
+        SRI_HIP(hipEventCreateWithFlags(&applied[i], hipEventDisableTiming));
+        SRI_HIP(hipEventCreateWithFlags(&returned[i], hipEventDisableTiming));
+      }
+    }
+    if (doubles_per_slot > slot_doubles) {
+      for (int i = 0; i < SLOTS; ++i) {
+        if (dX[i]) (void)hipFree(dX[i]);
+        if (dY[i]) (void)hipFree(dY[i]);
+        dX[i] = dY[i] = nullptr;
+      }
+      slot_doubles = 0;
+      for (int i = 0; i < SLOTS; ++i) {
+        if (hipMalloc(&dX[i], doubles_per_slot * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
+        if (hipMalloc(&dY[i], doubles_per_slot * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
+      }
+      slot_doubles = doubles_per_slot;
+    }
+    if (base > base_doubles) {
+      if (dB) (void)hipFree(dB);
+      dB = nullptr;
+      base_doubles = 0;
+      if (hipMalloc(&dB, base * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
+      base_doubles = base;
+    }
+    return SRI_OK;
+  }
+  void drain() {
+    if (s_in) (void)hipStreamSynchronize(s_in);
+    if (s_run) (void)hipStreamSynchronize(s_run);
+    if (s_out) (void)hipStreamSynchronize(s_out);
+  }
+  ~HostPipe() {
+    drain();
+    for (int i = 0; i < SLOTS; ++i) {
+      if (dX[i]) (void)hipFree(dX[i]);
+      if (dY[i]) (void)hipFree(dY[i]);
+      if (landed[i]) (void)hipEventDestroy(landed[i]);
+      if (applied[i]) (void)hipEventDestroy(applied[i]);
+      if (returned[i]) (void)hipEventDestroy(returned[i]);
+    }
+    if (dB) (void)hipFree(dB);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_run) (void)hipStreamDestroy(s_run);
+    if (s_out) (void)hipStreamDestroy(s_out);
+  }
+};
+
+// Page-locks [ptr, ptr + bytes) for the lifetime of the object; a no-op when the range is already registered (by the
+// caller, or because X and Y overlap) or cannot be (then the copies fall back to HIP's pageable path), and for small
+// buffers: those share heap pages with their neighbours (two registrations of one page do not nest) and gain nothing.
+struct PinnedRange {
+  static constexpr size_t kMinBytes = size_t(1) << 20;
+  void* ptr = nullptr;
+  PinnedRange(const void* p, size_t bytes) {
+    if (p == nullptr || bytes < kMinBytes) return;
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void*>(p);
+    else (void)hipGetLastError();
+  }
+  ~PinnedRange() {
+    if (ptr && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();   // never leave an error for the next launch check
+  }
+  PinnedRange(const PinnedRange&) = delete;
+  PinnedRange& operator=(const PinnedRange&) = delete;
+};
+
+static size_t host_block_columns(size_t rows, size_t M) {
+  // 4..32 MiB per block (the link is at 90 % of its rate from 4 MiB on, 98 % at 32 MiB), at least ~8 blocks per call so
+  // that the three streams overlap, whole 128-column tiles.
+  const size_t col_bytes = rows * sizeof(double);
+  const size_t total = col_bytes * M;
+  size_t target = total / 8;
+  target = std::min<size_t>(std::max<size_t>(target, size_t(4) << 20), size_t(32) << 20);
+  size_t cols = std::max<size_t>(target / col_bytes, 1);
+  cols = (cols + 127) & ~size_t(127);
+  return std::min(cols, (M + 127) & ~size_t(127));
+}
+
 static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x_base, double* Y, size_t ldy, size_t M) {
   if (h == nullptr || (M > 0 && (X == nullptr || Y == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
   if (M == 0) return SRI_OK;
-  sri::DeviceGuard guard;
+  DeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
   const size_t rows = h->rows;
-  const size_t ldd = (rows + 1) & ~static_cast<size_t>(1);   // even leading dimension: DMA path when rows % 16 == 0
-  double *dX = nullptr, *dY = nullptr, *dB = nullptr;
-  auto done = [&](int code) {
-    if (dX) (void)hipFree(dX);
-    if (dY) (void)hipFree(dY);
-    if (dB) (void)hipFree(dB);
-    return code;
-  };
-  if (hipMalloc(&dX, ldd * M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
-  if (hipMalloc(&dY, ldd * M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
-  if (x_base != nullptr) {
-    if (hipMalloc(&dB, M * sizeof(double)) != hipSuccess) return done(SRI_ENOMEM);
-    if (hipMemcpy(dB, x_base, M * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(SRI_EHIP);
+  // Device image of a block.  A contiguous host panel is copied as it lies (one linear copy per block; the kernel takes
+  // any leading dimension); a strided one is compacted by a 2-D copy to an even leading dimension.
+  const bool x_linear = ldx == rows, y_linear = ldy == rows;
+  const size_t ldd_x = x_linear ? rows : ((rows + 1) & ~size_t(1));
+  const size_t ldd_y = y_linear ? rows : ((rows + 1) & ~size_t(1));
+  const size_t cb = host_block_columns(rows, M);
+  if (h->pipe == nullptr) h->pipe = new (std::nothrow) HostPipe();
+  if (h->pipe == nullptr) return SRI_ENOMEM;
+  HostPipe& pp = *h->pipe;
+  rc = pp.reserve(std::max(ldd_x, ldd_y) * cb, x_base != nullptr ? M : 0);
+  if (rc != SRI_OK) return rc;
+
+  PinnedRange pin_x(X, ((M - 1) * ldx + rows) * sizeof(double));
+  PinnedRange pin_y(Y, ((M - 1) * ldy + rows) * sizeof(double));
+  PinnedRange pin_b(x_base, x_base != nullptr ? M * sizeof(double) : 0);
+
+  auto fail = [&](int code) { pp.drain(); return code; };
+#define PIPE_HIP(call)                                           \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) {                                     \
+      g_last_hip_error = static_cast<int>(e__);                  \
+      (void)hipGetLastError();                                   \
+      if (std::getenv("SRI_DEBUG")) std::fprintf(stderr, "sri host pipe: %s -> %s\n", #call, hipGetErrorString(e__)); \
+      return fail(SRI_EHIP);                                     \
+    }                                                            \
+  } while (0)
+
+  if (x_base != nullptr) PIPE_HIP(hipMemcpyAsync(pp.dB, x_base, M * sizeof(double), hipMemcpyHostToDevice, pp.s_in));
+  size_t b = 0;
+  for (size_t c0 = 0; c0 < M; c0 += cb, ++b) {
+    const int slot = static_cast<int>(b % HostPipe::SLOTS);
+    const size_t cols = std::min(cb, M - c0);
+    const bool reuse = b >= static_cast<size_t>(HostPipe::SLOTS);
+    // in: slot's X image is free once the apply that read it (block b - SLOTS) is done
+    if (reuse) PIPE_HIP(hipStreamWaitEvent(pp.s_in, pp.applied[slot], 0));
+    if (x_linear) {
+      PIPE_HIP(hipMemcpyAsync(pp.dX[slot], X + c0 * ldx, cols * rows * sizeof(double), hipMemcpyHostToDevice, pp.s_in));
+    } else {
+      PIPE_HIP(hipMemcpy2DAsync(pp.dX[slot], ldd_x * sizeof(double), X + c0 * ldx, ldx * sizeof(double), rows * sizeof(double),
+                                cols, hipMemcpyHostToDevice, pp.s_in));
+    }
+    PIPE_HIP(hipEventRecord(pp.landed[slot], pp.s_in));
+    // run: needs the block, and the slot's Y image back on the host (block b - SLOTS)
+    PIPE_HIP(hipStreamWaitEvent(pp.s_run, pp.landed[slot], 0));
+    if (reuse) PIPE_HIP(hipStreamWaitEvent(pp.s_run, pp.returned[slot], 0));
+    rc = run(h, pp.dX[slot], ldd_x, pp.dY[slot], ldd_y, cols, x_base != nullptr ? pp.dB + c0 : nullptr, pp.s_run);
+    if (rc != SRI_OK) return fail(rc);
+    PIPE_HIP(hipEventRecord(pp.applied[slot], pp.s_run));
+    // out
+    PIPE_HIP(hipStreamWaitEvent(pp.s_out, pp.applied[slot], 0));
+    if (y_linear) {
+      PIPE_HIP(hipMemcpyAsync(Y + c0 * ldy, pp.dY[slot], cols * rows * sizeof(double), hipMemcpyDeviceToHost, pp.s_out));
+    } else {
+      PIPE_HIP(hipMemcpy2DAsync(Y + c0 * ldy, ldy * sizeof(double), pp.dY[slot], ldd_y * sizeof(double), rows * sizeof(double),
+                                cols, hipMemcpyDeviceToHost, pp.s_out));
+    }
+    PIPE_HIP(hipEventRecord(pp.returned[slot], pp.s_out));
   }
-  if (hipMemcpy2D(dX, ldd * sizeof(double), X, ldx * sizeof(double), rows * sizeof(double), M, hipMemcpyHostToDevice) != hipSuccess)
-    return done(SRI_EHIP);
-  rc = sri::run(h, dX, ldd, dY, ldd, M, dB, nullptr);
-  if (rc != SRI_OK) return done(rc);
-  if (hipMemcpy2D(Y, ldy * sizeof(double), dY, ldd * sizeof(double), rows * sizeof(double), M, hipMemcpyDeviceToHost) != hipSuccess)
-    return done(SRI_EHIP);
-  return done(SRI_OK);
+  PIPE_HIP(hipStreamSynchronize(pp.s_out));                  // the last thing in every chain
+  PIPE_HIP(hipStreamSynchronize(pp.s_run));
+  PIPE_HIP(hipStreamSynchronize(pp.s_in));
+#undef PIPE_HIP
+  return SRI_OK;
 }
 
+}  // namespace sri
+
+extern "C" {
+
 int sri_apply_host(sri_apply_t* h, const double* X, size_t ldx, double* Y, size_t ldy, size_t M) {
-  return run_host(h, X, ldx, nullptr, Y, ldy, M);
+  return sri::run_host(h, X, ldx, nullptr, Y, ldy, M);
 }
 
 int sri_integrate_host(sri_apply_t* h, const double* B, size_t ldb, const double* x_base, double* Y, size_t ldy, size_t M) {
   if (h == nullptr || h->which != SRI_OP_DNN_INV || x_base == nullptr) return SRI_EINVAL;
-  return run_host(h, B, ldb, x_base, Y, ldy, M);
+  return sri::run_host(h, B, ldb, x_base, Y, ldy, M);
 }
 
 int sri_apply_destroy(sri_apply_t* h) {
@@ -1451,6 +1607,7 @@ int sri_apply_destroy(sri_apply_t* h) {
   if (h->d_apack) (void)hipFree(h->d_apack);
   if (h->d_apack_small) (void)hipFree(h->d_apack_small);
   if (h->d_w) (void)hipFree(h->d_w);
+  delete h->pipe;
   delete h;
   return SRI_OK;
 }

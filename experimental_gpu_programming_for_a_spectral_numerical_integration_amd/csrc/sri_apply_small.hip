@@ -285,9 +285,9 @@ int small_launch(const double* d_apack, const double* dX, size_t ldx, double* dY
   Args args{d_apack, dX, dY, d_tips, ldx, ldy, M, static_cast<uint32_t>(tiles),
             (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u};
   const unsigned grid = static_cast<unsigned>(tiles);                 // one tile per workgroup
-  hipLaunchKernelGGL(apply_small_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, static_cast<hipStream_t>(stream), args);
-  hipError_t e = hipGetLastError();
+  hipError_t e = launch_kernel(apply_small_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, static_cast<hipStream_t>(stream), args);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     record_hip_error(static_cast<int>(e));
     return SRI_EHIP;
   }

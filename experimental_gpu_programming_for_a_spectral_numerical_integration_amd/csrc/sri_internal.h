@@ -87,6 +87,25 @@ inline constexpr int k_of_ascending(int j, int g, int e) { return 8 * j + 4 * e 
 inline constexpr int k_of_paired(int j, int g, int e) { return 8 * j + 2 * g + e; }
 
 #if defined(SRI_DEVICE_HELPERS)   /* defined by the .hip translation units after <hip/hip_runtime.h> */
+}  // namespace sri
+#include <tuple>
+#include <utility>
+namespace sri {
+// Enqueue `kernel` and return the launch's OWN status.  (hipLaunchKernelGGL + hipGetLastError reports whatever failed
+// last on this thread — also a call of the application's, or a refused hipHostRegister — as a failed launch.)
+template <class... Params, class... Args, size_t... I>
+inline hipError_t launch_kernel_impl(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                     std::index_sequence<I...>, Args&&... args) {
+  std::tuple<Params...> values{static_cast<Params>(std::forward<Args>(args))...};
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(values))...};
+  return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, stream);
+}
+template <class... Params, class... Args>
+inline hipError_t launch_kernel(void (*kernel)(Params...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+  static_assert(sizeof...(Params) == sizeof...(Args), "one argument per kernel parameter");
+  return launch_kernel_impl(kernel, grid, block, lds, stream, std::index_sequence_for<Params...>{}, std::forward<Args>(args)...);
+}
+
 // G = 1/2 A(K) q of main.cpp:71-84 with hk = K/2:  A(K) = [0 -k0 -k1 -k2; k0 0 k2 -k1; k1 -k2 0 k0; k2 k1 -k0 0].
 // One product and two fused multiply-adds per component — f64 VALU work shares the MFMA pipe.  The stand-alone
 // kernel of sri_rod.hip and the fused epilogue of sri_apply.hip use the same

@@ -478,9 +478,8 @@ int sri_rod_strain_field(sri_rod_t* h, const double* d_qe, size_t rods, double* 
   sri::RodDeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  hipLaunchKernelGGL(sri::strain_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     h->m, rods, h->d_nodes, d_qe, dK, ldk);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::strain_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h->m, rods, h->d_nodes, d_qe, dK, ldk));
   return SRI_OK;
 }
 
@@ -492,9 +491,8 @@ int sri_rod_quaternion_rhs(sri_rod_t* h, const double* dK, size_t ldk, const dou
   sri::RodDeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  hipLaunchKernelGGL(sri::quat_rhs_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     h->m, rods, dK, ldk, dQ, ldq, dG, ldg);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::quat_rhs_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h->m, rods, dK, ldk, dQ, ldq, dG, ldg));
   return SRI_OK;
 }
 
@@ -517,9 +515,8 @@ int sri_rod_quaternion_step(sri_rod_t* h, const double* d_qe, const double* dG, 
   }
   rc = sri::integrate_quat_step(h->integ, dG, ldg, d_q_base, epi, dG_next, ldn, 4 * rods, d_tips, stream, &partials);
   if (rc != SRI_OK || d_update == nullptr) return rc;
-  hipLaunchKernelGGL(sri::fold_partials_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_partial, partials,
-                     reinterpret_cast<unsigned long long*>(d_update));
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::fold_partials_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), h->d_partial, partials,
+                     reinterpret_cast<unsigned long long*>(d_update)));
   return SRI_OK;
 }
 
@@ -529,9 +526,8 @@ int sri_rod_position_rhs(sri_rod_t* h, const double* dQ, size_t ldq, size_t rods
   sri::RodDeviceGuard guard;
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  hipLaunchKernelGGL(sri::position_rhs_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     h->m, rods, dQ, ldq, dB, ldb);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::position_rhs_kernel, dim3(sri::blocks_for(rods * h->m, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     h->m, rods, dQ, ldq, dB, ldb));
   return SRI_OK;
 }
 
@@ -557,9 +553,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   const size_t cols = 4 * rods;
 
   // xb = the base value of every column
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
-                     qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                     qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4));
   const size_t ldw = h->ldw;
   double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = ldw)
   double* nxt = h->d_Qa;
@@ -579,9 +574,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
                                       stream_);
     if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
       const dim3 grid(static_cast<unsigned>((rods + sri::kProlongRods - 1) / sri::kProlongRods), (m + 255) / 256);
-      hipLaunchKernelGGL(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
-                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, ldw, h->d_tips + cols);
-      ROD_HIP(hipGetLastError());
+      ROD_HIP(sri::launch_kernel(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
+                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, ldw, h->d_tips + cols));
       predicted = true;
     } else if (rcc != SRI_OK && rcc != SRI_ENOTCONVERGED) {
       return rcc;
@@ -591,9 +585,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     // Q^0 = q_init at every node (in the caller's panel), G^0 = 1/2 A(K) Q^0
     rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, ldw, stream);
     if (rc != SRI_OK) return rc;
-    hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
-                       qi[0], qi[1], qi[2], qi[3], dQ, ldq, static_cast<double*>(nullptr));
-    ROD_HIP(hipGetLastError());
+    ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
+                       qi[0], qi[1], qi[2], qi[3], dQ, ldq, static_cast<double*>(nullptr)));
     rc = sri_rod_quaternion_rhs(h, h->d_K, ldw, dQ, ldq, rods, cur, ldw, stream);
     if (rc != SRI_OK) return rc;
   }
@@ -615,9 +608,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   hipEvent_t* const done = h->done;
   // tips of Q^0 (what iteration 0 compares with): q_init in every column, or what the predictor left there
   if (!predicted) {
-    hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
-                       qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr));
-    ROD_HIP(hipGetLastError());
+    ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                       qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr)));
   }
   ROD_HIP(hipMemsetAsync(h->d_state, 0, 4 * sizeof(unsigned long long), stream));
   // From the predictor's start the error is rounding-level noise spread over the whole rod, not a Picard transient that
@@ -636,9 +628,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       int r = sri::integrate_quat_step(h->integ, bufs[k & 1], ldw, h->d_xb4, epi, bufs[(k + 1) & 1], ldw, cols,
                                        h->d_tips + (k & 1) * cols, stream, &partials);
       if (r != SRI_OK) return r;
-      hipLaunchKernelGGL(sri::picard_control_kernel, dim3(1), dim3(256), 0, stream, h->d_partial, partials, tip_tol,
-                         static_cast<unsigned long long>(max_iter), h->d_state);
-      ROD_HIP(hipGetLastError());
+      ROD_HIP(sri::launch_kernel(sri::picard_control_kernel, dim3(1), dim3(256), 0, stream, h->d_partial, partials, tip_tol,
+                         static_cast<unsigned long long>(max_iter), h->d_state));
     }
     ROD_HIP(hipMemcpyAsync(h_state + 4 * slot, h->d_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipEventRecord(done[slot], stream));
@@ -653,9 +644,8 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     int r = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
     if (r != SRI_OK) return r;
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
-                       ldw, h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw);
-    ROD_HIP(hipGetLastError());
+    ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
+                       ldw, h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw));
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipStreamSynchronize(stream));
     std::memcpy(&upd, h_state, sizeof(double));
@@ -704,9 +694,8 @@ int sri_rod_integrate_positions(sri_rod_t* h, const double* dQ, size_t ldq, size
   const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
   const double* ri = r_init ? r_init : r0;
   const size_t cols = 3 * rods;
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 3u,
-                     ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 3u,
+                     ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
   rc = sri_rod_position_rhs(h, dQ, ldq, rods, h->d_B, h->ldw, stream);
   if (rc != SRI_OK) return rc;
   return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
@@ -742,9 +731,8 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
   const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
   const double* ri = r_init ? r_init : r0;
   const size_t cols = 3 * rods;
-  hipLaunchKernelGGL(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
-                     cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3);
-  ROD_HIP(hipGetLastError());
+  ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
+                     cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
   return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
 }
 

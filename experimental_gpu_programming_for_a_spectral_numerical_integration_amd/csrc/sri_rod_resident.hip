@@ -321,8 +321,7 @@ static int resident_launch(ResidentRod* h, ResidentArgs args, hipStream_t stream
   grid = wgs_needed < grid ? wgs_needed : grid;
   if (grid > h->cap_blocks) return SRI_EUNSUPPORTED;
   *blocks_out = static_cast<uint32_t>(grid);
-  hipLaunchKernelGGL((rod_resident_kernel<TM, TN, NW>), dim3(static_cast<unsigned>(grid)), dim3(G::THREADS), G::LDS_BYTES, stream, args);
-  RES_HIP(hipGetLastError());
+  RES_HIP(sri::launch_kernel((rod_resident_kernel<TM, TN, NW>), dim3(static_cast<unsigned>(grid)), dim3(G::THREADS), G::LDS_BYTES, stream, args));
   return SRI_OK;
 }
 

@@ -134,8 +134,11 @@ int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_
 int sri_integrate_tips(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
                        double *dY, size_t ldy, size_t M, double *d_tips, void *hip_stream);
 
-/* Convenience for callers holding HOST buffers: stages X through device memory, applies,
- * copies Y back, synchronises.  (PCIe-inclusive; never what bench.py times.) */
+/* For callers holding HOST panels (what include/chebyshev_differentiation.h calls): the panel crosses PCIe in
+ * blocks of columns on three streams — block b+1 on its way in, block b applied, block b-1 on its way back — so a
+ * call costs about one direction of the link, not in + apply + out.  X and Y are page-locked for the duration of the
+ * call (ranges the caller registered itself are left alone; if locking fails the copies take HIP's pageable path).
+ * Y may be X (in place).  Returns when Y is complete.  (PCIe-inclusive; never what bench.py times.) */
 int sri_apply_host(sri_apply_t *h, const double *X, size_t ldx, double *Y, size_t ldy, size_t M);
 
 /* Host-buffer form of sri_integrate (x_base: M host doubles). */
