@@ -144,7 +144,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(n: int, budget_s: float, data: str):
+def cpu_baseline(n: int, budget_s: float, data: str, max_rods: int = 65536):
     """Oracle (kind "port") on a bounded sample of the same workload: single thread like the
     reference's main.cpp, then all host cores; >= 3 repetitions each, min and median."""
     import oracle
@@ -155,8 +155,8 @@ def cpu_baseline(n: int, budget_s: float, data: str):
     oracle.apply(A, Xp)                                   # warm
     t0 = time.perf_counter(); oracle.apply(A, Xp); t = time.perf_counter() - t0
     rate = probe_rods / max(t, 1e-9)
-    reps = 3
-    rods = int(min(max(rate * budget_s * 0.6 / reps, probe_rods), 32768))
+    reps = 5
+    rods = int(min(max(rate * budget_s * 0.6 / reps, probe_rods), max_rods))   # at most the workload itself
     X = host_panel(n, rods, data, 0x5EED)
     t1 = []
     for _ in range(reps):
@@ -538,7 +538,7 @@ def main():
         if gather_ok is not None:
             out["gathered_state_verified"] = gather_ok
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, args.data)
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, args.data, rods)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
