@@ -796,10 +796,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       since_store = 99;
     }
     ++tseq_c;
+    if constexpr ((ABL & 256) == 0) {                           // ABL & 256: keep accumulating (what the zeroing costs)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+    }
   };
   auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
     slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;

@@ -185,6 +185,8 @@ int main(int argc, char** argv) {
   ablate<32>("early group stores nothing", a, col_tiles, blocks, flops, dS);
   ablate<64>("late group stores nothing", a, col_tiles, blocks, flops, dS);
   ablate<128>("stores alias one tile (no HBM writes)", a, col_tiles, blocks, flops, dS);
+  ablate<256>("accumulators never zeroed", a, col_tiles, blocks, flops, dS);
+  ablate<260>("no Y stores, never zeroed", a, col_tiles, blocks, flops, dS);
   ablate<16>("staggered start (b%8)/8 tile", a, col_tiles, blocks, flops, dS);
   ablate<0>("none again", a, col_tiles, blocks, flops, dS);
   ablate<16>("staggered start again", a, col_tiles, blocks, flops, dS);
