@@ -353,10 +353,14 @@ def main():
     lib, stream0 = sri.load_library(), torch.cuda.current_stream().cuda_stream
 
     def step(i: int, ev_pair=None):
-        if not use_dist and ev_pair is None:
-            # single GPU, no per-launch events: the bare C-ABI call (a few-microsecond kernel is launch-bound otherwise)
+        if ev_pair is None and (not use_dist or args.gather in ("final", "none")):
+            # no per-launch events, no per-step exchange: the bare C-ABI call (a few-microsecond kernel is launch-bound
+            # otherwise, and N > 1 must not pay more per step than N = 1 does)
             k = i % nrot
-            rc = lib.sri_apply(op._h, Xs[k].data_ptr(), rows, Ys[k].data_ptr(), rows, M, stream0)
+            if use_dist and args.gather == "final":
+                rc = lib.sri_apply_tips(op._h, Xs[k].data_ptr(), rows, Ys[k].data_ptr(), rows, M, tips_local[i & 1].data_ptr(), stream0)
+            else:
+                rc = lib.sri_apply(op._h, Xs[k].data_ptr(), rows, Ys[k].data_ptr(), rows, M, stream0)
             if rc != 0:
                 raise sri.SriError(rc, "sri_apply")
             return
@@ -394,6 +398,13 @@ def main():
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
+    if use_dist and args.gather != "none":
+        # the data-path collective once, untimed: RCCL sets up its channels on a communicator's first collective
+        # (hundreds of ms), which would otherwise land in the timed region of `--gather final`
+        if args.gather == "full":
+            all_gather(full_all, Y)
+        else:
+            all_gather(tips_all[0], tips_local[0])
     fence()
     # Kernel duration by HIP events on the launch stream: one pair per launch — except for kernels of a few microseconds
     # (config 2), where an event pair per launch costs more than the kernel: there ONE pair brackets the K launches and the
