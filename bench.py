@@ -419,14 +419,15 @@ def main():
     # (an event pair costs ~5 us of stream time: bracketing every launch would lengthen every step by 1 %, so every
     # `--event-stride`-th launch is bracketed and the kernel's duration is the mean over those)
     stride = max(1, args.event_stride)
+    first = stride // 2                                     # not the first launches of the region: they start from an idle GPU
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range((args.steps + stride - 1) // stride if per_launch_events else 1)]
+              for _ in range(max(1, (args.steps - first + stride - 1) // stride) if per_launch_events else 1)]
     whole = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
     whole[0].record()
     if per_launch_events:
         for i in range(args.steps):
-            step(i, events[i // stride] if i % stride == 0 else None)
+            step(i, events[(i - first) // stride] if (i >= first and (i - first) % stride == 0) or (args.steps <= first and i == 0) else None)
     else:
         events[0] = whole
         for i in range(args.steps):
