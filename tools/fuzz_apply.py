@@ -64,6 +64,11 @@ def main():
         if rng.random() < 0.3:                                   # smooth columns: the cancellation-heavy kind
             t = np.linspace(-1, 1, rows)
             Xh[:, :rows] = np.cos(np.outer(rng.uniform(0.2, 3, M), t) + rng.uniform(0, 6, (M, 1)))
+        u = rng.random()
+        if u < 0.08:
+            Xh[:, :rows] *= 2.0 ** -1015                         # results and partial sums in the subnormal range: no flush to zero
+        elif u < 0.12:
+            Xh[:, :rows] *= 2.0 ** 900                           # large but finite
         xbuf = torch.full((offx + M * ldx + 8,), float("nan"), dtype=torch.float64, device=dev)
         xbuf[offx:offx + M * ldx] = torch.from_numpy(Xh.reshape(-1)).to(dev)
         ybuf = torch.full((offy + M * ldy + 8,), -7.25, dtype=torch.float64, device=dev)
