@@ -602,7 +602,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // Once the loop has stopped, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
   // CONFIRMED on the whole panel:  max |1/2 A(K) Q - G|  bounds the next update of every entry of Q, because
   // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
-  const uint32_t kChunk = predicted ? 4u : 8u;                  // iterations enqueued per read-back of the loop state
+  const uint32_t kChunk = predicted ? 2u : 8u;                  // iterations enqueued per read-back of the loop state
   double* bufs[2] = {cur, nxt};                                 // iteration k reads bufs[k & 1], writes bufs[(k + 1) & 1]
   unsigned long long* const h_state = h->h_state;               // 2 slots x 4 words, pinned; owned by the handle
   hipEvent_t* const done = h->done;
