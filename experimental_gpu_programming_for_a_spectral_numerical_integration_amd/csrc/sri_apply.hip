@@ -163,6 +163,17 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// The same with the address split as the instruction takes it: a wave-uniform 64-bit base (SGPR pair) plus a per-lane
+// 32-bit byte offset (one VGPR) — `global_load_lds_dwordx4 v_off, s[base:base+1]`.  All per-stage address arithmetic of
+// the stage stream is then scalar: none of it competes with the MFMAs for the vector ALU (a 64-bit VALU add per piece
+// and the column multiplies of the tile change did: 36-49 VALU instructions per wave and stage).  The empty asm keeps
+// hipcc from folding base + offset back into one loop-invariant 64-bit VGPR pointer.
+// (By reference: the asm "rewrites" the caller's own register, so no copy is made per piece.)
+__device__ __forceinline__ void lds_dma16_sv(const char* uniform_base, uint32_t& lane_offset, void* lds_dst) {
+  asm volatile("" : "+v"(lane_offset));
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_base + lane_offset),
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 // (A non-temporal / sc0 cache policy on the X-panel pieces — read once, so that they would not evict the operator from
 // L2 — was measured at N = 1024, where the operator is re-streamed 2.6 x: 0.4-0.8 % slower; N = 256: no change.)
 
@@ -276,26 +287,38 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // DMA: instruction i (= wid + it*NW) covers columns 8i..8i+7 of the tile; this lane writes
   // piece position (lane & 7) of column 8i + (lane >> 3), which must hold source piece
   // (lane & 7) ^ sigma(column).
-  const char* xsrc[DMA ? G::X_DMA_PER_WAVE : 1];
+  // Addresses of the LDS-DMA pieces: wave-uniform bases (scalar registers, advanced per stage and per tile by the scalar
+  // ALU) + per-lane 32-bit offsets that only change at the panel's last column tile (clamp).  The host guarantees that
+  // a tile's column span fits 32 bits (BN * ldx * 8 < 2^32).
+  uint32_t xoff[DMA ? G::X_DMA_PER_WAVE : 1];
   int xsafe[(DMA && TAIL) ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
-  const char* asrc;
+  const char* xbase = nullptr;                       // p.x + first column of the tile (uniform)
+  const char* abase = nullptr;                       // operator slab of the tile's row block (uniform)
+  uint32_t aoff = static_cast<uint32_t>(lane) * 16u;
+  const uint32_t ldx_bytes = static_cast<uint32_t>(p.ldx * sizeof(double));
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
   uint32_t tseq_i = 0;       // EPI_QUAT: how many tiles the issue cursor has left behind (selects the qe side buffer)
   uint32_t tseq_c = 0;       // ... and how many tiles this wave has finished (side buffer of the one in the accumulators)
   double tip_update = 0.0;   // EPI_QUAT monitor: largest |tip - previous tip| this lane has seen over all its tiles
   size_t col0_i = 0;
   auto issue_setup = [&]() __attribute__((always_inline)) {
-    const uint32_t rb = tile_i / p.col_tiles;
-    col0_i = static_cast<size_t>(tile_i % p.col_tiles) * G::BN;
-    asrc = reinterpret_cast<const char*>(p.apack) + static_cast<size_t>(rb) * p.nk * G::A_BYTES + lane * 16;
+    // Once per tile.  Everything below hangs on the opaque copy of the tile index, so that hipcc cannot hoist the
+    // division and the multiplies out of the branch and run them in every stage (it did: if-conversion).
+    uint32_t tile_o = tile_i;
+    asm volatile("" : "+s"(tile_o) : : "memory");
+    const uint32_t rb = tile_o / p.col_tiles;
+    col0_i = static_cast<size_t>(tile_o % p.col_tiles) * G::BN;
+    abase = reinterpret_cast<const char*>(p.apack) + static_cast<size_t>(rb) * p.nk * G::A_BYTES;
     if constexpr (DMA) {
+      xbase = reinterpret_cast<const char*>(p.x + col0_i * p.ldx);
+      const size_t left = last_col - col0_i;                      // columns of the panel behind the tile's first one
+      const uint32_t lim = left < static_cast<size_t>(G::BN) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(G::BN);
 #pragma unroll
       for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
-        const int cc = (wid + it * NW) * 8 + (lane >> 3);
-        const int piece = (lane & 7) ^ ((cc >> 1) & SWZ);
-        size_t col = col0_i + cc;
-        col = col < last_col ? col : last_col;          // clamp: tail columns re-read a valid one
-        xsrc[it] = reinterpret_cast<const char*>(p.x + col * p.ldx) + piece * 16;
+        const uint32_t cc = static_cast<uint32_t>((wid + it * NW) * 8 + (lane >> 3));
+        const uint32_t piece = static_cast<uint32_t>(lane & 7) ^ ((cc >> 1) & SWZ);
+        const uint32_t ccl = cc < lim ? cc : lim;                 // clamp: tail columns re-read a valid one
+        xoff[it] = ccl * ldx_bytes + piece * 16u;
         // In the last k chunk of a panel whose row count is not a multiple of 16, a piece that holds a k
         // beyond the last row reaches into the next column — or, for the panel's last column, past the end of the
         // buffer: THAT one is fetched from the same piece of the PREVIOUS chunk instead (a full chunk of the same
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // Only the LAST column of the panel needs that: behind every other column lies the next one (or the padding of a
         // strided panel), so the piece can be fetched where it is — its valid element arrives by DMA like any other and
         // fixup_tail() only overwrites the foreign one.
-        if constexpr (TAIL) xsafe[it] = (col0_i + cc >= last_col && 2 * piece + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
+        if constexpr (TAIL) xsafe[it] = (cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -359,23 +382,31 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto stage_issue = [&]() __attribute__((always_inline)) {
     issue_qe();
     char* sA = smem + slot_i * G::STAGE_BYTES;
-    const char* gA = asrc + static_cast<size_t>(kc_i) * G::A_BYTES;
+    const char* gA = abase + static_cast<size_t>(kc_i) * G::A_BYTES;
     if (!(ABL & 1) || abl_first) {
 #pragma unroll
       for (int it = 0; it < G::A_DMA_PER_WAVE; ++it) {
         const int i = wid + it * NW;
-        lds_dma16(gA + i * 1024, sA + i * 1024);
+        lds_dma16_sv(gA + i * 1024, aoff, sA + i * 1024);
       }
     }
     if constexpr (DMA) {
       char* sX = sA + G::A_BYTES;
+      const char* gX = xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES;
       if (!(ABL & 2) || abl_first) {
 #pragma unroll
         for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
           const int i = wid + it * NW;
-          int back = 0;
-          if constexpr (TAIL) back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
-          lds_dma16(xsrc[it] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sX + i * 1024);
+          if constexpr (TAIL) {
+            // last chunk: the chunk's offset moves into the lane offset, so that the step back cannot wrap below zero
+            // (kc_i >= 1 there: rows >= 17)
+            const bool last = kc_i + 1 == p.nk;
+            const uint32_t kb = last ? kc_i * static_cast<uint32_t>(X_ROW_BYTES) : 0u;
+            uint32_t voff = xoff[it] + kb - (last ? static_cast<uint32_t>(xsafe[it]) : 0u);
+            lds_dma16_sv(last ? xbase : gX, voff, sX + i * 1024);
+          } else {
+            lds_dma16_sv(gX, xoff[it], sX + i * 1024);
+          }
         }
       }
       if constexpr (ABL != 0) abl_first = false;
@@ -399,15 +430,20 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if (idx < G::A_DMA_PER_WAVE) {
       if (!(ABL & 1) || abl_first) {
         const int i = wid + idx * NW;
-        lds_dma16(asrc + static_cast<size_t>(kc_i) * G::A_BYTES + i * 1024, sA + i * 1024);
+        lds_dma16_sv(abase + static_cast<size_t>(kc_i) * G::A_BYTES + i * 1024, aoff, sA + i * 1024);
       }
     } else {
       if (!(ABL & 2) || abl_first) {
         const int it = idx - G::A_DMA_PER_WAVE;
         const int i = wid + it * NW;
-        int back = 0;
-        if constexpr (DMA && TAIL) back = (kc_i + 1 == p.nk) ? xsafe[it] : 0;
-        lds_dma16(xsrc[DMA ? it : 0] + static_cast<size_t>(kc_i) * X_ROW_BYTES - back, sA + G::A_BYTES + i * 1024);
+        if constexpr (DMA && TAIL) {
+          const bool last = kc_i + 1 == p.nk;                   // see stage_issue
+          const uint32_t kb = last ? kc_i * static_cast<uint32_t>(X_ROW_BYTES) : 0u;
+          uint32_t voff = xoff[it] + kb - (last ? static_cast<uint32_t>(xsafe[it]) : 0u);
+          lds_dma16_sv(last ? xbase : xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, voff, sA + G::A_BYTES + i * 1024);
+        } else {
+          lds_dma16_sv(xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, xoff[DMA ? it : 0], sA + G::A_BYTES + i * 1024);
+        }
       }
       if constexpr (ABL != 0) { if (idx == G::DMA_PER_WAVE - 1) abl_first = false; }
     }
@@ -1308,6 +1344,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // of 16 is handled by the tail fix-up.  Only tiny operators (< 16 rows: no full chunk to fall back on) use
   // the register-staged build.
   const bool dma = h->rows >= 16;
+  // the LDS-DMA pieces address a tile as a uniform 64-bit base + a 32-bit lane offset: 128 columns must span < 4 GiB
+  if (dma && (static_cast<unsigned long long>(ldx) * 8ull * 128ull + static_cast<unsigned long long>(h->rows) * 8ull) >= (1ull << 32))
+    return SRI_EUNSUPPORTED;
   args.tail_k = h->rows % 16;
   args.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
   h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);

@@ -111,8 +111,9 @@ int sri_apply_dim(const sri_apply_t *h, uint32_t *rows);
 
 /* Enqueue Y = A * X on `hip_stream` (a hipStream_t, NULL = the device's null stream).
  * dX, dY: device pointers, column-major rows x M, ldx, ldy >= rows.  X and Y must not overlap.
- * M may be any value >= 0; no alignment requirement (16-byte aligned pointers with even leading
- * dimensions and rows % 16 == 0 take the LDS-DMA fast path). */
+ * M may be any value >= 0; no alignment requirement beyond that of a double (panels whose columns start on
+ * 128-byte lines additionally get non-temporal stores).  Leading dimensions up to 4 194 000 doubles (128 columns
+ * must span less than 4 GiB: SRI_EUNSUPPORTED beyond). */
 int sri_apply(sri_apply_t *h, const double *dX, size_t ldx, double *dY, size_t ldy, size_t M,
               void *hip_stream);
 
