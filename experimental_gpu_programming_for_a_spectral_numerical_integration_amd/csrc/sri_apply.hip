@@ -191,6 +191,19 @@ __device__ __forceinline__ void store_y(d2* p, d2 v) {
   else *p = v;
 }
 
+// The two doubles of a 16-byte Y store come from two different accumulators and have to be copied side by side:
+// two 64-bit moves instead of the four 32-bit ones hipcc emits for the tuple (every VALU instruction costs MFMA time).
+__device__ __forceinline__ d2 pack2(double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double a, b;
+  asm("v_mov_b64 %0, %1" : "=v"(a) : "v"(lo));
+  asm("v_mov_b64 %0, %1" : "=v"(b) : "v"(hi));
+  return d2{a, b};
+#else
+  return d2{lo, hi};
+#endif
+}
+
 // Diagnostic builds: keep a register value opaque/live without emitting an instruction.  (The "v"
 // constraint only exists for the device pass; the host pass parses kernel bodies too.)
 template <class T>
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 v0 -= wv[t][0] * xbv;
                 v1 -= wv[t][1] * xbv;
               }
-              if (all_rows || row + 1 < p.rows) store_y<NT>(reinterpret_cast<d2*>(yp), d2{v0, v1});   // 16 B, 8-byte aligned is fine
+              if (all_rows || row + 1 < p.rows) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
               else *yp = v0;                                                                 // the lane holding the last row
             }
           }
