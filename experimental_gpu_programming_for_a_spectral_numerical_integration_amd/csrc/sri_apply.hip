@@ -502,13 +502,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // Ascending k: one 8-byte X read per MFMA.  The per-tile offsets are kept opaque: seen as constants 2 KiB apart,
   // hipcc pairs the reads of two tiles into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and,
   // banked mod 32 over 128-byte rows, with 2-way conflicts (measured: -2 % at N = 256).
-  int xrd[ASCK ? TN : 1];
+  // Every vector-ALU instruction in the stage loop costs MFMA time, so the per-lane part of a read address is formed
+  // once — xq[j][e] for instruction (j, e): element g & 1 of piece 4j + 2e + (g >> 1) of this lane's column — the slot
+  // base is ONE add per (j, e) and stage, and the column tile is an immediate offset; an empty asm between the reads of
+  // two tiles keeps them apart.
+  int xq[ASCK ? 2 : 1][2];
   if constexpr (ASCK) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      xrd[tn] = x_off + tn * 16 * X_ROW_BYTES + (g & 1) * 8;
-      keep_live(xrd[tn]);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) xq[j][e] = x_off + (g & 1) * 8 + ((4 * j + 2 * e + (g >> 1)) ^ sig) * 16;
   }
 
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
@@ -535,9 +538,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // instruction (j, e) sums k = 8j + 4e + g over the lanes' k slots g: element g & 1 of piece 4j + 2e + (g >> 1)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int xoff = ((4 * j + 2 * e + (g >> 1)) ^ sig) * 16;
+        const char* rd = base + xq[ASCK ? j : 0][e];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn][e] = *reinterpret_cast<const double*>(base + xrd[tn] + xoff);
+        for (int tn = 0; tn < TN; ++tn) {
+          b[tn][e] = *reinterpret_cast<const double*>(rd + tn * 16 * X_ROW_BYTES);
+          asm volatile("" ::: "memory");                         // no ds_read2st64_b64 out of two of these
+        }
       }
     } else {
       const int xpiece = ((4 * j + g) ^ sig) * 16;
