@@ -94,7 +94,10 @@ constexpr int X_ROW_BYTES = BK * 8;  // one column of the X stage: 128 B = 8 pie
 // Both orders are reproduced bit for bit by a CPU model in the test tree (a chain of four fused multiply-adds per MFMA).
 // Measured and dropped: ascending order from 16-byte reads + v_permlane16_swap_b32 (two 32-bit VALU moves per fragment
 // exchange the halves between adjacent 16-lane rows): correct, but 2.1 % slower than the 8-byte reads.
-constexpr uint32_t kAscendingAboveRows = 512;
+#ifndef SRI_ASCENDING_ABOVE_ROWS
+#define SRI_ASCENDING_ABOVE_ROWS 512   // A/B knob (tools/ab_apply.py): 0 = ascending wherever the variant exists, 1 << 30 = never
+#endif
+constexpr uint32_t kAscendingAboveRows = SRI_ASCENDING_ABOVE_ROWS;
 inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_ascending(j, g, e) : k_of_paired(j, g, e); }
 #ifndef SRI_SCHED_HINTS
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
@@ -499,9 +502,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
   const int sig = ((cs >> 1) & SWZ);
   const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
-  // Ascending k: one 8-byte X read per MFMA.  The per-tile offsets are kept opaque: seen as constants 2 KiB apart,
-  // hipcc pairs the reads of two tiles into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and,
-  // banked mod 32 over 128-byte rows, with 2-way conflicts (measured: -2 % at N = 256).
+  // Ascending k: one 8-byte X read per MFMA.  Seen as plain loads 2 KiB apart, the reads of two column tiles are paired
+  // by hipcc into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and, banked mod 32 over 128-byte
+  // rows, with 2-way conflicts (measured: -2 % at N = 256).
   // Every vector-ALU instruction in the stage loop costs MFMA time, so the per-lane part of a read address is formed
   // once — xq[j][e] for instruction (j, e): element g & 1 of piece 4j + 2e + (g >> 1) of this lane's column — the slot
   // base is ONE add per (j, e) and stage, and the column tile is an immediate offset; an empty asm between the reads of
