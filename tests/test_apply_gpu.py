@@ -158,6 +158,8 @@ def test_empty_and_error_paths(sri):
     assert lib.sri_apply(op._h, good.data_ptr(), 63, good.data_ptr(), 64, 4, None) == -1   # ld < rows
     assert lib.sri_apply(None, good.data_ptr(), 64, good.data_ptr(), 64, 4, None) == -1
     assert lib.sri_integrate(op._h, good.data_ptr(), 64, good.data_ptr(), good.data_ptr(), 64, 4, None) == -1  # not DNN_INV
+    # a tile's 128 columns must span less than 4 GiB (32-bit lane offsets of the LDS-DMA pieces): refused before any launch
+    assert lib.sri_apply(op._h, good.data_ptr(), 5_000_000, good.data_ptr(), 64, 100_000, None) == -6   # SRI_EUNSUPPORTED
 
 
 @pytest.mark.parametrize("n", [16, 64, 256])
