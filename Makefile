@@ -12,7 +12,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # measurement tooling (not product code); binaries land in build/ (git-ignored, travels with gpurun)
-tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe build/small_diag build/stream_probe build/host_transfer_probe build/store_mfma_interleave
+tools: build/mfma_f64_probe build/apply_diag build/store_rate_probe build/small_diag build/stream_probe build/host_transfer_probe build/store_mfma_interleave build/valu_mfma_cost
 
 build/mfma_f64_probe: tools/mfma_f64_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -include algorithm $< -o $@
@@ -33,6 +33,9 @@ build/host_transfer_probe: tools/host_transfer_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -pthread $< -o $@
 
 build/store_mfma_interleave: tools/store_mfma_interleave.hip
+	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
+
+build/valu_mfma_cost: tools/valu_mfma_cost.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
 
 clean:
