@@ -23,7 +23,8 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-enum { K_NONE, K_MOV32, K_MOV64, K_ADD32, K_ADD64, K_MUL32, K_FMA64, K_SALU, K_CNDMASK };
+enum { K_NONE, K_MOV32, K_MOV64, K_ADD32, K_ADD64, K_MUL32, K_FMA64, K_SALU, K_CNDMASK, K_DSREAD128, K_DSREAD64 };
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 template <int KIND, int K, bool SPREAD = false>
 __global__ __launch_bounds__(512) void k(double* dst, int iters, unsigned long long* cyc) {
@@ -36,6 +37,12 @@ __global__ __launch_bounds__(512) void k(double* dst, int iters, unsigned long l
   unsigned long long w0 = lane, w1 = lane * 5;
   double f0 = lane, f1 = 1.0;
   unsigned s0 = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) char lds[8 * 16384];
+  for (int i = threadIdx.x; i < 8 * 16384 / 8; i += 512) reinterpret_cast<double*>(lds)[i] = 1.0;
+  __syncthreads();
+  const unsigned rd = (threadIdx.x >> 6) * 16384 + lane * 16;   // contiguous 1 KiB per read: conflict-free
+  d2 sink2 = {0, 0};
+  double sink1 = 0;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -59,10 +66,13 @@ __global__ __launch_bounds__(512) void k(double* dst, int iters, unsigned long l
       if (KIND == K_FMA64) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(f0) : "v"(f1));
       if (KIND == K_SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
       if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(v0) : "v"(v1) : "vcc");
+      if (KIND == K_DSREAD128) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink2) : "v"(rd), "n"((j & 15) * 1024));
+      if (KIND == K_DSREAD64) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(sink1) : "v"(rd), "n"((j & 15) * 1024));
     }
+    if (KIND == K_DSREAD128 || KIND == K_DSREAD64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  double sum = f0 + static_cast<double>(v0) + static_cast<double>(w0) + static_cast<double>(s0);
+  double sum = sink2[0] + sink1 + f0 + static_cast<double>(v0) + static_cast<double>(w0) + static_cast<double>(s0);
 #pragma unroll
   for (int i = 0; i < 16; ++i) sum += acc[i][0];
   if (sum == 12345.678) dst[0] = 1;
@@ -105,6 +115,8 @@ int main() {
   kind<K_MUL32>("v_mul_lo_u32", dst, cyc, base);
   kind<K_FMA64>("v_fma_f64", dst, cyc, base);
   kind<K_CNDMASK>("v_cndmask_b32", dst, cyc, base);
+  kind<K_DSREAD128>("ds_read_b128", dst, cyc, base);
+  kind<K_DSREAD64>("ds_read_b64", dst, cyc, base);
   kind<K_SALU>("s_add_u32 (scalar)", dst, cyc, base);
   // the same count, two behind every MFMA instead of 32 in a row behind the 16th
   const double sv = run<K_ADD32, 32, true>(dst, cyc), ss = run<K_SALU, 32, true>(dst, cyc);
