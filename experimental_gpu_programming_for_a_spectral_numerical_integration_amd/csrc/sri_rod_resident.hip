@@ -21,8 +21,10 @@
 // Waves of a workgroup share only the read-only operator: after one barrier they run independently.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -305,19 +307,26 @@ template <int TM, int TN, int NW>
 static int resident_launch(ResidentRod* h, ResidentArgs args, hipStream_t stream, uint32_t* blocks_out) {
   using G = ResGeo<TM, TN, NW>;
   const auto kern = &rod_resident_kernel<TM, TN, NW>;
-  static bool prepared[16] = {};
-  static int per_cu[16] = {};
+  // blocks per CU of this geometry, per device: written once under the lock (handles of several devices may take their
+  // first launch from different host threads), read lock-free afterwards
+  static std::atomic<int> per_cu[16] = {};
+  static std::mutex prepare_lock;
   if (h->device < 0 || h->device >= 16) return SRI_EUNSUPPORTED;
-  if (!prepared[h->device]) {
-    RES_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    int nb = 0;
-    RES_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
-    per_cu[h->device] = nb < 1 ? 1 : nb;
-    prepared[h->device] = true;
+  int resident_blocks = per_cu[h->device].load(std::memory_order_acquire);
+  if (resident_blocks == 0) {
+    std::lock_guard<std::mutex> guard(prepare_lock);
+    resident_blocks = per_cu[h->device].load(std::memory_order_acquire);
+    if (resident_blocks == 0) {
+      RES_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+      int nb = 0;
+      RES_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, G::LDS_BYTES));
+      resident_blocks = nb < 1 ? 1 : nb;
+      per_cu[h->device].store(resident_blocks, std::memory_order_release);
+    }
   }
   const size_t ntasks = (args.rods + G::RODS_PER_TASK - 1) / G::RODS_PER_TASK;
   const size_t wgs_needed = (ntasks + NW - 1) / NW;
-  size_t grid = static_cast<size_t>(h->num_cus) * per_cu[h->device];
+  size_t grid = static_cast<size_t>(h->num_cus) * resident_blocks;
   grid = wgs_needed < grid ? wgs_needed : grid;
   if (grid > h->cap_blocks) return SRI_EUNSUPPORTED;
   *blocks_out = static_cast<uint32_t>(grid);
