@@ -23,11 +23,13 @@
 //   * The X fragment is the MFMA's first operand, i.e. every tile is accumulated TRANSPOSED: the 16
 //     lanes of a quarter-wave hold 16 rows of one column, and interleaving the rows of two stacked
 //     tiles (row_of_slot) gives each lane two adjacent rows, so Y leaves in 16-byte stores that
-//     are 256 contiguous bytes per quarter-wave.  k is consumed in ASCENDING order, the reference's own
-//     (main.cpp:172): MFMA (k pair j, element e) sums k = 8j + 4e + g over the lanes' k slots g, fed by 8-byte
-//     X-fragment reads (sri_internal.h: k_of_ascending; the 16-byte alternative sums equal-parity k's together
-//     and is measurably less accurate on smooth fields).  The row permutation and the k order are folded into the
-//     host-side packing of A; X and Y keep the caller's plain column-major layout.
+//     are 256 contiguous bytes per quarter-wave.  The k order inside a block of 8 is a property of the handle
+//     (sri_apply_summation_order): operators of up to 512 rows — the headline N = 256 among them — and every Dn_NN^-1
+//     take 16-byte X-fragment reads, so one MFMA sums four k of EQUAL PARITY (evens before odds: 0,2,4,6 | 1,3,5,7;
+//     sri_internal.h: k_of_paired); differentiation operators of more than 512 rows sum in the reference's own
+//     ASCENDING order (main.cpp:172) from 8-byte reads (k_of_ascending), because on smooth fields under D_1024 the
+//     paired order is measurably less accurate (see "The k order of a launch" below).  The row permutation and the
+//     k order are folded into the host-side packing of A; X and Y keep the caller's plain column-major layout.
 //   * PERSISTENT: one 512-thread workgroup per CU (256 x 128 tile, 2 waves per SIMD, 144 KiB LDS
 //     ring of 3 stages, 2 in flight) walks tiles b, b+grid, ...; the (tile, k chunk) pairs form one
 //     stream that keeps flowing across tile boundaries.  Stages are awaited with counted
@@ -1083,6 +1085,12 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
               if (row < rows && k < rows) out[o] = A[row + static_cast<size_t>(k) * lda];
               else if (w != nullptr && row < rows && k == rows) out[o] = -w[row];
             }
+#ifdef SRI_TEST_CORRUPT_OPERATOR
+  // `make broken` only (never in libsri_hip.so): one operator entry off by 2^-20 relative, so that a test can show
+  // bench.py's parity gate turning a wrong kernel into a non-zero exit code.
+  for (double& v : out)
+    if (v != 0.0) { v *= 1.0 + 0x1p-20; break; }
+#endif
 }
 
 // Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
@@ -1263,8 +1271,9 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->geo = rows <= 64 ? GEO_FLAT : (rows <= 128 ? GEO_MID : GEO_TALL);
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
-  // and fused-step variants are built on) keeps the faster paired order at every size.
-  h->ascending = rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
+  // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant only
+  // exists for the tall geometry — what is reported is always what pack_operator() and dispatch() use.
+  h->ascending = h->geo == GEO_TALL && rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
   h->bm = h->geo == GEO_FLAT ? GeoFlat::BM : (h->geo == GEO_MID ? GeoMid::BM : GeoTall::BM);
   h->nk = (rows + BK - 1) / BK;
   h->row_blocks = (rows + h->bm - 1) / h->bm;

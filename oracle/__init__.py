@@ -238,3 +238,64 @@ def integrate_position(n: int, Q: np.ndarray, r_init=None) -> np.ndarray:
 
 QE_MAIN_CPP = np.array([0, 0, 0, 1.2877691307032, -1.63807499160786, 0.437406679142598, 0, 0, 0], dtype=np.float64)
 """The hard-coded strain coordinates of main.cpp:187-195."""
+
+
+# ---- the parity gate of the apply (BASELINE.md §4) — ONE definition, used by tests/conftest.py and bench.py -----------
+FRO_TOL = 1e-12                       # north_star: <= 1e-12 relative (Frobenius)
+GATE_FRO = "fro<=1e-12"
+GATE_CANCELLATION = "cancellation-limited: <=2e-12 and closer to binary128 than the reference"
+
+
+def backward_tol(n: int) -> float:
+    """max |E_ij| / (|A||X|)_ij <= 8 N 2^-53."""
+    return 8.0 * n * 2.0 ** -53
+
+
+def parity_gate(A: np.ndarray, X: np.ndarray, Y: np.ndarray, n: int, *, ascending: bool, cancellation_limited: bool = False,
+                exact: bool = True) -> dict:
+    """Checks a product Y (what the HIP path returned for A @ X) and reports; never raises.  In decreasing strength:
+
+    1. bit for bit equal to the CPU model of the kernel's arithmetic (sri_mfma_model.c): a chain of fused multiply-adds
+       over k in the order the handle reports (`ascending`: the reference's own order, main.cpp:172; else evens before
+       odds inside every block of 8 k);
+    2. against this oracle (multiply, then add) <= 1e-12 in the Frobenius norm and <= 8 N 2^-53 backward error;
+    3. ONLY where the caller declares the regime `cancellation_limited` — smooth rod-strain fields under the
+       differentiation operator D_N at N >= 1024, where this oracle itself is 0.9e-12 from the true product, so two
+       correct fp64 results may differ by more than 1e-12 — a Frobenius distance above 1e-12 is accepted if it is
+       <= 2e-12 AND the result is no farther from a binary128 product than the oracle is.
+    `exact=False` skips the binary128 product (seconds at N = 1024); the cancellation tier then cannot pass.
+    Returns {"ok", "gate", "failures", "fro_vs_oracle", "backward", "backward_bound", "bit_exact_vs_fma_model", ...}."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    Yref = apply(A, X, threads=0)
+    E = Y - Yref
+    fro = float(np.linalg.norm(E) / max(np.linalg.norm(Yref), np.finfo(float).tiny))
+    scale = np.abs(A) @ np.abs(X)
+    scale[scale == 0] = np.finfo(float).tiny
+    back = float(np.max(np.abs(E) / scale))
+    model = MODEL_ASCENDING_FMA if ascending else MODEL_KERNEL
+    bit_exact = bool(np.array_equal(Y, model_apply(A, X, model)))
+    out = {"ok": True, "gate": GATE_FRO, "failures": [], "fro_vs_oracle": fro, "backward": back,
+           "backward_bound": backward_tol(n), "bit_exact_vs_fma_model": bit_exact, "ascending_k": bool(ascending)}
+    if not np.all(np.isfinite(Y)) and np.all(np.isfinite(Yref)):
+        out["failures"].append("non-finite values in the result")
+    if not bit_exact:
+        out["failures"].append("differs from the FMA-chain model of the kernel (" + ("ascending" if ascending else "paired") + " k order)")
+    if not back <= backward_tol(n):
+        out["failures"].append(f"backward error {back:.3e} > {backward_tol(n):.3e}")
+    need_exact = exact and (not fro <= FRO_TOL or cancellation_limited)
+    if need_exact:
+        Yx = apply_exact(A, X)
+        nx = max(np.linalg.norm(Yx), np.finfo(float).tiny)
+        out["gpu_vs_binary128"] = float(np.linalg.norm(Y - Yx) / nx)
+        out["oracle_vs_binary128"] = float(np.linalg.norm(Yref - Yx) / nx)
+    if not fro <= FRO_TOL:
+        if cancellation_limited and need_exact:
+            out["gate"] = GATE_CANCELLATION
+            if not (fro <= 2e-12 and out["gpu_vs_binary128"] <= out["oracle_vs_binary128"]):
+                out["failures"].append(f"fro {fro:.3e}: gpu {out['gpu_vs_binary128']:.3e} vs oracle {out['oracle_vs_binary128']:.3e} from binary128")
+        else:
+            out["failures"].append(f"fro {fro:.3e} > 1e-12" + (" (cancellation tier not checked: binary128 product skipped)"
+                                                                if cancellation_limited else ""))
+    out["ok"] = not out["failures"]
+    return out

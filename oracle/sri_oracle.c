@@ -1,8 +1,11 @@
 /*
  * sri_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
  *
- * A plain-C restatement, operation for operation, of the reference's spectral-integration hot
- * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * A plain-C restatement of the reference's spectral-integration hot path: the reference's OWN
+ * arithmetic (chebyshev_differentiation.h:19-108, the slicing and rank-1 lines of main.cpp) operation
+ * for operation; the third-party arithmetic it calls (Eigen's LU inverse and dense product, Boost's
+ * legendre_p — listed below) in the same ALGORITHM CLASS (unblocked partial-pivot LU, strictly
+ * sequential k), not instruction for instruction: Eigen blocks and vectorises both.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * The product library (libsri_hip.so) never links, calls or falls back to anything in here.
  *
  * PARITY UNPINNED: the reference (aGotelli/experimental_gpu_programming_for_a_spectral_numerical_

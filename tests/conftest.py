@@ -73,15 +73,15 @@ def parity_metrics(A: np.ndarray, X: np.ndarray, Y: np.ndarray, Yref: np.ndarray
     return float(fro), back
 
 
-FRO_TOL = 1e-12                      # north_star: <= 1e-12 relative
+FRO_TOL = 1e-12                      # north_star: <= 1e-12 relative (oracle.FRO_TOL is the same number)
 
 
 def backward_tol(n: int) -> float:   # 8 N 2^-53
     return 8.0 * n * 2.0 ** -53
 
 
-def assert_apply_parity(oracle, A, X, Y, n, what="", ascending=None):
-    """The parity gate of the apply, in decreasing strength:
+def assert_apply_parity(oracle, A, X, Y, n, what="", ascending=None, kind=None, which=None):
+    """The parity gate of the apply — `oracle.parity_gate`, the same function bench.py exits non-zero on:
 
     1. bit for bit equal to the CPU model of the kernel's arithmetic (oracle/sri_mfma_model.c): every output element is
        a chain of fused multiply-adds — v_mfma_f64_16x16x4_f64 is four FMAs over its k slots — over k in the order the
@@ -89,25 +89,15 @@ def assert_apply_parity(oracle, A, X, Y, n, what="", ascending=None):
        operators of more than 512 rows, else evens before odds inside every block of 8 k;
     2. against the CPU oracle (multiply, then add: two roundings per term) <= 1e-12 in the Frobenius norm and
        <= 8 N 2^-53 in the backward error max |E| / (|A||X|);
-    3. where the oracle ITSELF is not within 1e-12 of the true product — the smooth rod field under D_1024
-       (||D||_inf = 2.1e6, |Y| ~ 1: the oracle is 9.4e-13 away from a binary128 product), so two correct fp64 results may
-       differ by more than 1e-12 — the Frobenius bound is replaced by: GPU no farther from the binary128 product than
-       the oracle is, and within 2e-12 of the oracle.
+    3. ONLY for smooth rod-strain fields (`kind == "rod"`) under the differentiation operator (`which == 0`, D_N) at
+       N >= 1024 — where the oracle ITSELF is 9.4e-13 away from a binary128 product (||D||_inf = 2.1e6, |Y| ~ 1), so two
+       correct fp64 results may differ by more than 1e-12 — the Frobenius bound is replaced by: GPU no farther from the
+       binary128 product than the oracle is, and within 2e-12 of the oracle.  Uniform panels and the integration
+       operators (measured there: 1e-16) never take that tier.
     Returns the measured figures."""
-    Yref = oracle.apply(A, X, threads=0)
-    fro, back = parity_metrics(A, X, Y, Yref)
     if ascending is None:
         ascending = A.shape[0] > 512
-    model = oracle.MODEL_ASCENDING_FMA if ascending else oracle.MODEL_KERNEL
-    bit_exact = bool(np.array_equal(Y, oracle.model_apply(A, X, model)))
-    out = {"fro_vs_oracle": fro, "backward": back, "bit_exact_vs_fma_model": bit_exact, "ascending_k": bool(ascending)}
-    assert bit_exact, (what, "differs from the FMA-chain model", "ascending" if ascending else "paired", fro)
-    assert back <= backward_tol(n), (what, back)
-    if fro > FRO_TOL:
-        Yx = oracle.apply_exact(A, X)
-        err_gpu = float(np.linalg.norm(Y - Yx) / np.linalg.norm(Yx))
-        err_cpu = float(np.linalg.norm(Yref - Yx) / np.linalg.norm(Yx))
-        out.update(gpu_vs_binary128=err_gpu, oracle_vs_binary128=err_cpu)
-        assert n >= 1024, (what, fro)
-        assert err_gpu <= err_cpu and fro <= 2e-12, (what, fro, err_gpu, err_cpu)
+    limited = kind == "rod" and which == 0 and n >= 1024
+    out = oracle.parity_gate(A, X, Y, n, ascending=ascending, cancellation_limited=limited)
+    assert out["ok"], (what, out["failures"], out)
     return out

@@ -66,7 +66,7 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
     assert op.rows == rows
     Y = _run(op, X)
     assert op.ascending_k == (rows > 512 and which != 1)
-    assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, kind, op.last_kernel), ascending=op.ascending_k)
+    assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, kind, op.last_kernel), ascending=op.ascending_k, kind=kind, which=which)
     expect_dma = rows >= 16          # every panel of >= 16 rows takes the LDS-DMA build, whatever its alignment
     assert ("dma" in op.last_kernel) == expect_dma, op.last_kernel
 
@@ -270,7 +270,7 @@ def _full_size_checks(sri, oracle, n, rods, kind="uniform"):
     ti = torch.from_numpy(idx).cuda()
     Xs = np.asfortranarray(X[ti].cpu().numpy().T)
     Ys = np.asfortranarray(Y[ti].cpu().numpy().T)
-    assert_apply_parity(oracle, A, Xs, Ys, n, what=("full size", n, rods, kind))
+    assert_apply_parity(oracle, A, Xs, Ys, n, what=("full size", n, rods, kind), ascending=op.ascending_k, kind=kind, which=0)
     # (2) linearity: A(aX1 + X2) == a A X1 + A X2 up to rounding of the combination
     X2 = torch.rand((M, n), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     Y2 = op.apply(X2)

@@ -15,13 +15,16 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
-def _run(cmd, env=None):
-    e = dict(os.environ, **(env or {}))
-    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+def _run(cmd, env=None, rc=0, drop=()):
+    e = {k: v for k, v in dict(os.environ, **(env or {})).items() if k not in drop}
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == rc, (r.returncode, r.stderr[-2000:])
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, r.stdout                       # ONE JSON line, nothing else on stdout
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    assert d["exit_code"] == rc
+    d["_stderr"] = r.stderr
+    return d
 
 
 def test_single_gpu_line():
@@ -82,3 +85,60 @@ def test_config_presets_and_data_kinds():
     assert cb["reps"] >= 3 and cb["median_value"] <= cb["value"] and cb["all_cores_median_value"] <= cb["all_cores_value"]
     d = _run([sys.executable, "bench.py", "--data", "uniform"] + SMALL)
     assert d["config"]["panel_data"] == "uniform" and "uniform" in d["config"]["workload"]
+
+
+TORCHRUN_ENV = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")
+
+
+def test_config4_eight_rank_rehearsal_at_the_real_per_rank_shape():
+    """BASELINE config 4 — the one configuration this pool cannot run — exactly as the driver will invoke it, on the one
+    device: 8 ranks x 65 536 rods per rank (the real per-rank shape; the first ranks run the apply on cuda:0, the rest are
+    GPU-less ghost ranks because a box admits six processes on its card), collectives staged over gloo.  The line must
+    say 8 GPUs / config 4, and every rank's slab of the gathered final state must sit at its own offset."""
+    d = _run([sys.executable, "bench.py", "--gpus", "8", "--config", "4", "--steps", "5", "--warmup", "2"],
+             env={"SRI_BENCH_REHEARSAL": "1", "SRI_BENCH_REHEARSAL_GPU_RANKS": "4"}, drop=TORCHRUN_ENV)
+    assert KEYS <= set(d) and d["n_gpus"] == 8 and d["steps"] == 5 and d["warmup"] == 2
+    c = d["config"]
+    assert c["baseline_config"] == 4 and c["N"] == 256 and c["rods_per_gpu"] == 65536 and c["gather"] == "final"
+    assert "8 GPUs" in c["workload"] and "ghost" in c["collective"]
+    assert d["gathered_state_verified"] is True and d["gathered_slabs_wrong"] == []
+    assert d["parity"]["ok"] is True and d["parity"]["gate"] == "fro<=1e-12" and d["parity"]["bit_exact_vs_cpu_model_of_the_kernel"]
+    # compute-only and end-to-end figures side by side (SURVEY 8(e) i / ii)
+    assert d["ms_per_step_compute_only"] > 0 and d["final_gather_ms"] >= 0 and d["value_compute_only"] >= d["value"]
+    assert "cpu_baseline" not in d                         # rank 0 at N = 1 only
+
+
+def test_single_gpu_line_is_a_superset_of_round_2s():
+    d = _run([sys.executable, "bench.py"] + SMALL)
+    r2 = {"traffic", "traffic_source", "achieved_TFLOPs", "kernel_ms", "kernel_ms_method", "kernel_ms_single_launch_bracket",
+          "kernel_ms_launch_to_launch", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "hbm_algorithmic_GBps",
+          "hbm_frac_of_8TBps", "bound", "achieved", "peak", "unit", "frac"}
+    assert r2 <= set(d["roofline"])
+    assert abs(d["roofline"]["frac_of_measured_peak"] - d["roofline"]["achieved"] / 77.5) < 1e-12
+    assert {"columns_sampled", "gpu_vs_cpu_oracle_fro", "gpu_vs_binary128_fro", "cpu_oracle_vs_binary128_fro", "k_order",
+            "bit_exact_vs_cpu_model_of_the_kernel", "gate", "backward", "ok"} <= set(d["parity"])
+    assert "ms_per_step_compute_only" not in d and "degraded" not in d
+
+
+@pytest.mark.parametrize("inject", ["comm_fail", "comm_hang", "comm_probe_fail"])
+def test_a_broken_communicator_never_ends_in_rc_0(inject):
+    """sri_comm_create failing, hanging, or RCCL not loadable on a rank: the measurement is still printed (from torch's
+    RCCL, marked degraded), the rank and its error are named on stderr, and the exit code is 3."""
+    d = _run([sys.executable, "bench.py", "--gather", "final"] + SMALL,
+             env={"SRI_BENCH_FORCE_DIST": "1", "SRI_BENCH_INJECT": inject, "SRI_COMM_TIMEOUT_S": "3"}, rc=3)
+    assert "sri_comm unavailable" in d["degraded"] and "rank 0" in d["degraded"]
+    assert "DEGRADED" in d["config"]["collective"] and d["gathered_state_verified"] is True
+    assert "rank 0: sri_comm unavailable" in d["_stderr"]
+
+
+def test_bench_exits_nonzero_when_the_parity_gate_fails():
+    """(1) the right kernel checked against the WRONG arithmetic model; (2) a deliberately broken build of the library
+    (one operator entry off by 2^-20 relative: `make -C csrc broken`) checked against the right one.  Both: rc 2."""
+    d = _run([sys.executable, "bench.py"] + SMALL, env={"SRI_BENCH_FORCE_MODEL": "ascending"}, rc=2)
+    assert d["parity"]["ok"] is False and d["parity"]["bit_exact_vs_cpu_model_of_the_kernel"] is False
+    assert "PARITY GATE FAILED" in d["_stderr"]
+    csrc = os.path.join(ROOT, "experimental_gpu_programming_for_a_spectral_numerical_integration_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "broken"], stdout=subprocess.DEVNULL)
+    d = _run([sys.executable, "bench.py", "--no-verify"] + SMALL,
+             env={"SRI_HIP_LIBRARY": os.path.join(ROOT, "build", "libsri_hip_broken.so")}, rc=2)
+    assert d["parity"]["ok"] is False and d["parity"]["failures"]

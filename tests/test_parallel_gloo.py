@@ -87,3 +87,43 @@ def test_sharded_apply_reassembles_over_gloo(rods):
 def test_ragged_gather_needs_counts():
     assert parallel.shard_counts(28, 2, granule=4) == [16, 12]
     assert parallel.shard_counts(24, 2, granule=4) == [12, 12]
+
+
+def _config4_worker(rank, world, port, M, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+
+        first, count = parallel.shard_columns(M * world, world, rank, granule=4)
+        assert (first, count) == (rank * M, M)                      # equal shards: rank r owns columns [r M, (r+1) M)
+        tips = bench.ghost_tips(rank, M, torch)
+        out = torch.empty(M * world, dtype=torch.float64)
+        got, _ = parallel.gather_tip_state(tips.reshape(M, 1), out=out)
+        mine_ok = torch.equal(out[first:first + count], tips)
+        if rank == 0:
+            bad = bench.slab_report(out, world, M, 0, torch)         # every slab is a ghost pattern here
+            swapped = out.clone()
+            swapped[M:2 * M], swapped[2 * M:3 * M] = out[2 * M:3 * M], out[M:2 * M]
+            q.put((bool(mine_ok), bad, bench.slab_report(swapped, world, M, 0, torch)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_shape_eight_ranks_over_gloo():
+    """BASELINE config 4 as the exchange sees it: 8 ranks x 65 536 rods x 4 columns = 2 097 152 global columns, 2 MiB of tip
+    state per rank.  The reassembly and the per-slab check bench.py applies to it, at the real offsets (CPU, gloo)."""
+    world, M = 8, 4 * 65536
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    mine_ok, bad, bad_swapped = q.get(timeout=5)
+    assert mine_ok and bad == [] and bad_swapped == [1, 2]
