@@ -448,7 +448,8 @@ def run_rank(args, world_env) -> int:
     def elapsed_ms(a, b):
         return 0.0 if a is None else a.elapsed_time(b)
 
-    lib = sri.load_library()
+    # (a ghost rank must not even LOAD the library: registering its code objects opens the GPU, and the box counts that)
+    lib = None if ghost else sri.load_library()
     stream0 = None if ghost else torch.cuda.current_stream().cuda_stream
 
     def step(i: int, ev_pair=None):
@@ -738,6 +739,17 @@ def run_rank(args, world_env) -> int:
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
 
+    if ghost:
+        # self-check of the rehearsal's premise: a ghost rank has never opened the GPU
+        fds = []
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                fds.append(os.readlink(f"/proc/self/fd/{fd}"))
+            except OSError:
+                pass
+        if any(t.startswith("/dev/kfd") or t.startswith("/dev/dri/") for t in fds):
+            print(f"bench.py: ghost rank {rank} holds a GPU device node open: {[t for t in fds if t.startswith('/dev/')]}", file=sys.stderr, flush=True)
+            rc = 5
     if use_dist:
         # every rank leaves with rank 0's verdict (torchrun reports the first failing rank; all agree here)
         v = torch.tensor([float(rc)], dtype=torch.float64, device=dev)
