@@ -334,10 +334,18 @@ def run_rank(args, world_env) -> int:
         if not ghost:
             torch.cuda.synchronize()
 
+    def barrier():
+        if rehearsal:
+            # (dist.barrier() initialises the GPU runtime even on a gloo group — measured: it opens /dev/kfd — which a
+            # ghost rank must never do; an all-reduce of one CPU word is the same rendezvous)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64))
+        else:
+            dist.barrier()
+
     def fence():
         sync()
         if use_dist:
-            dist.barrier()
+            barrier()
             sync()
 
     import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
@@ -757,7 +765,7 @@ def run_rank(args, world_env) -> int:
         rc = int(v.item())
         if degraded is not None and rc == EXIT_OK:
             rc = EXIT_COMM
-        dist.barrier()
+        barrier()
         if comm_hung:
             # a thread of this rank is stuck inside ncclCommInitRank and cannot be joined or cancelled: interpreter
             # shutdown would wait for RCCL's own teardown.  The line is out and flushed; leave with the failure code.
