@@ -8,8 +8,18 @@
 # PMC passes never use --sys-trace / runtime traces (gpurun refuses that combination).
 # Summaries land in profiles/<tag>_rocprofv3_{kernel_stats.csv,summary.json} and profiles/hbm_traffic_n<N>_r<rods>_<op>.json.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 shift || true
+# The profiled program must be the single-rank bench.py itself: with --gpus N > 1 bench.py starts torch.distributed.run as
+# a child of a process whose GPU the profiler's preloaded library has already initialised (in the --pmc passes) — the
+# launcher hop that must never sit behind `rocprofv3 --`.  Multi-GPU evidence comes from unprofiled runs.
+prev=""
+for a in "$@"; do
+  if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "profile_bench.sh: --gpus $a refused (profile the single-rank bench only)" >&2; exit 2; fi
+  case "$a" in --gpus=1) ;; --gpus=*) echo "profile_bench.sh: $a refused (profile the single-rank bench only)" >&2; exit 2;; esac
+  prev="$a"
+done
+if [ -n "$WORLD_SIZE" ] && [ "$WORLD_SIZE" != "1" ]; then echo "profile_bench.sh: WORLD_SIZE=$WORLD_SIZE refused" >&2; exit 2; fi
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out

@@ -85,6 +85,7 @@ if "hbm_bytes_per_launch" in summary and line is not None:
     summary["hbm_bytes_over_algorithmic"] = summary["hbm_bytes_per_launch"] / alg
     rec = {"n": cfg["N"], "rods": cfg["rods_per_gpu"], "operator": cfg["operator"],
            "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
+           "rocprofv3_kernel_avg_ns": summary.get("avg_ns"), "rocprofv3_kernel_calls": summary.get("calls"),
            "date": datetime.date.today().isoformat(),
            "source": f"profiles/{tag}_rocprofv3_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"}
     json.dump(rec, open(os.path.join(prof, f"hbm_traffic_n{cfg['N']}_r{cfg['rods_per_gpu']}_{cfg['operator']}.json"), "w"), indent=1)
