@@ -58,6 +58,7 @@
 #include <mutex>
 #include <new>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #define SRI_DEVICE_HELPERS 1
@@ -104,6 +105,13 @@ inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_asc
 #ifndef SRI_SCHED_HINTS
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
 #endif
+// A/B knobs of the tile end (tools/ab_apply.py; every combination gives bit-identical results):
+#ifndef SRI_STORE_SADDR
+#define SRI_STORE_SADDR 1            // 1: full tiles store through `global_store_dwordx4 v_off, v[..], s[base:base+1] offset:imm` —
+#endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
+#ifndef SRI_TILE_PRIO
+#define SRI_TILE_PRIO 0              // bit 0 / bit 1: the early / late wave group runs the MFMAs in front of its Y stores at raised priority
+#endif
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16; NSTAGE LDS ring slots.
 template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
@@ -132,7 +140,13 @@ struct Geo {
   static constexpr int TIPS_BYTES = BN * 8;                             // previous tip value of every column (convergence monitor)
   static constexpr int SIDE_BYTES = QE_BYTES + P1_BYTES + TIPS_BYTES;
   static constexpr int lds_bytes_quat(int bufs) { return LDS_BYTES + bufs * SIDE_BYTES; }
-  static_assert(LDS_BYTES + 2 * SIDE_BYTES <= 160 * 1024, "ring + side buffers exceed a CU");
+  // FOLD on the LDS-DMA path (sri_integrate of an operator with rows % 16 != 0): the x_base value of each of the tile's
+  // columns travels with the tile's first stage into a small buffer at the very end of the LDS allocation — 256 bytes per
+  // wave (the columns of that wave's own X pieces), two tiles in flight.
+  static constexpr int XB_WAVE_BYTES = 256;
+  static constexpr int XB_BYTES = 2 * NW * XB_WAVE_BYTES;
+  static_assert(8 * X_DMA_PER_WAVE * 8 <= XB_WAVE_BYTES, "one 8-byte entry per column of the wave's X pieces");
+  static_assert(LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024, "ring + side buffers exceed a CU");
   static_assert(P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 && (P1_BYTES + 1023) / 1024 + 1 <= NW,
                 "P1 slab and previous tips: at most one (half or whole) 1-KiB DMA piece per wave");
   static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
@@ -196,6 +210,31 @@ __device__ __forceinline__ void store_y(d2* p, d2 v) {
   else *p = v;
 }
 
+// Full-tile stores with the address split as the instruction takes it — wave-uniform 64-bit base (SGPR pair), constant
+// per-lane 32-bit byte offset (one VGPR for the whole kernel), 13-bit immediate for the row pair: the column step is
+// scalar arithmetic and nothing of a store's address is computed on the vector ALU (the C++ form costs three 64-bit
+// VALU adds per column pair, and hipcc guards every store of a tile whose row count it cannot see with an exec-mask
+// branch).  Inline asm because hipcc folds base + offset back into a 64-bit VGPR pointer.  The stores are not known
+// to the compiler's s_waitcnt insertion — neither are the LDS-DMA pieces' consumers: the kernel counts vmcnt itself.
+// Nor to its hazard recognizer: on gfx940+ a store of more than 8 bytes needs TWO wait states before a vector-ALU write of
+// its data registers (the next pack2 reuses them) — hence the s_nop 1 inside the statement (with one wait state the
+// 64-row kernel produced run-to-run different results).
+template <bool NT, int IMM>
+__device__ __forceinline__ void store16_sv(char* uniform_base, uint32_t lane_offset, d2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (NT && SRI_NT_STORES != 0)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+  else
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void store8_sv(char* uniform_base, uint32_t lane_offset, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+#endif
+}
+
 // The two doubles of a 16-byte Y store come from two different accumulators and have to be copied side by side:
 // two 64-bit moves instead of the four 32-bit ones hipcc emits for the tuple (every VALU instruction costs MFMA time).
 __device__ __forceinline__ d2 pack2(double lo, double hi) {
@@ -216,6 +255,33 @@ __device__ __forceinline__ void keep_live(T& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(v));
 #endif
+}
+
+// The kernel's argument block, read again from the kernarg segment through a pointer the compiler cannot see through:
+// the loads are emitted where the values are used (scalar loads, only of the fields that are used there) instead of once
+// at kernel entry.  The tile-boundary code (first stage of a tile, Y stores, tail fix-up) takes its ~25 argument words
+// this way: kept resident they pushed the stage loop past the 102 scalar registers of a wave, and every spilled word
+// is a v_readlane / v_writelane — vector-ALU instructions, i.e. MFMA time — in the middle of the MFMA stream.
+struct ApplyArgs;
+template <class Args>
+__device__ __forceinline__ Args reload_kernel_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __attribute__((address_space(4))) Args* base = (const __attribute__((address_space(4))) Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(base));
+  return *base;
+#else
+  return Args{};
+#endif
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ... — for values that must reach an instruction as immediates.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // Wait until all but the YOUNGER youngest vector-memory operations of this wave have completed
@@ -246,7 +312,8 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           4 = no Y stores, 8 = read LDS fragments only in the first stage,
 //           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts,
 //           32 = the early wave group stores nothing, 64 = the late wave group stores nothing,
-//           128 = all tiles store over the first column tile (store issue without HBM write traffic).
+//           128 = all tiles store over the first column tile (store issue without HBM write traffic),
+//           256 = accumulators never re-zeroed, 512 = (results stay correct) workgroups of one XCD start (b / 8 % 32) / 32 of a tile apart.
 //   EPI   : EPI_QUAT fuses the caller on the far side of the product into the store stage:
 //           the panel is 4 columns (w, x, y, z) per rod, Q = A X - w xb^T is the new quaternion iterate, and what
 //           is stored is the NEXT right-hand side G = 1/2 A(K) Q of main.cpp:71-84 with K = Phi(X_row) qe
@@ -273,6 +340,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr int SWZ = (EPI == EPI_QUAT && !ASCK) ? 6 : 7;
   constexpr bool FOLD = RANK1 && (TAIL || !DMA);
   constexpr bool RANK1_EPI = RANK1 && !FOLD;
+  constexpr bool XBUF = FOLD && DMA;                  // x_base rides through the LDS side buffer (Geo::XB_BYTES)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
@@ -281,6 +349,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     st_r0 = __builtin_amdgcn_s_memrealtime();
   }
 
+  if constexpr ((ABL & 512) != 0) {
+    // workgroups of ONE XCD (consecutive b / 8) start (b / 8 % 32) / 32 of a tile apart: no two CUs of an XCD end a tile together
+    const unsigned steps = ((blockIdx.x >> 3) % 32) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 32 / 8128;
+    for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   if constexpr ((ABL & 16) != 0) {
     // one tile = nk stages x 2*TM*TN MFMAs x 64 cycles x waves per SIMD; s_sleep 127 ~ 8128 cycles
     const unsigned steps = (blockIdx.x % 8) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 8 / 8128;
@@ -292,11 +365,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   }
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
+#ifndef SRI_WAVE_ROW_MAJOR
+#define SRI_WAVE_ROW_MAJOR 0         // A/B knob: 1 = a wave group (waves 0..NW/2-1 / the rest) owns ALL rows of half the tile's columns
+#endif
+  const int wm = SRI_WAVE_ROW_MAJOR ? wid % G::WM : wid / WN, wn = SRI_WAVE_ROW_MAJOR ? wid / G::WM : wid % WN;
   const int c = lane & 15, g = lane >> 4;
 
   const uint32_t ntiles = p.row_blocks * p.col_tiles;
-  const size_t last_col = p.m - 1;
   const uint32_t first_tile = blockIdx.x;      // host guarantees gridDim.x <= ntiles
   const uint32_t my_tiles = (ntiles - first_tile + gridDim.x - 1) / gridDim.x;
   const uint32_t total_stages = my_tiles * p.nk;
@@ -310,27 +385,33 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // a tile's column span fits 32 bits (BN * ldx * 8 < 2^32).
   uint32_t xoff[DMA ? G::X_DMA_PER_WAVE : 1];
   int xsafe[(DMA && TAIL) ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
+  bool edge_i = false;                                // TAIL: the tile under the issue cursor holds the panel's LAST column
+  bool tail_base0 = false;                            // TAIL: the chunk offset of the stage under the cursor sits in xoff[] (see cursor_advance)
   const char* xbase = nullptr;                       // p.x + first column of the tile (uniform)
   const char* abase = nullptr;                       // operator slab of the tile's row block (uniform)
   uint32_t aoff = static_cast<uint32_t>(lane) * 16u;
-  const uint32_t ldx_bytes = static_cast<uint32_t>(p.ldx * sizeof(double));
   uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
   uint32_t tseq_i = 0;       // EPI_QUAT: how many tiles the issue cursor has left behind (selects the qe side buffer)
   uint32_t tseq_c = 0;       // ... and how many tiles this wave has finished (side buffer of the one in the accumulators)
   double tip_update = 0.0;   // EPI_QUAT monitor: largest |tip - previous tip| this lane has seen over all its tiles
   size_t col0_i = 0;
   auto issue_setup = [&]() __attribute__((always_inline)) {
+    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
     // Once per tile.  Everything below hangs on the opaque copy of the tile index, so that hipcc cannot hoist the
     // division and the multiplies out of the branch and run them in every stage (it did: if-conversion).
     uint32_t tile_o = tile_i;
     asm volatile("" : "+s"(tile_o) : : "memory");
-    const uint32_t rb = tile_o / p.col_tiles;
-    col0_i = static_cast<size_t>(tile_o % p.col_tiles) * G::BN;
-    abase = reinterpret_cast<const char*>(p.apack) + static_cast<size_t>(rb) * p.nk * G::A_BYTES;
+    const uint32_t rb = tile_o / q.col_tiles;
+    col0_i = static_cast<size_t>(tile_o % q.col_tiles) * G::BN;
+    abase = reinterpret_cast<const char*>(q.apack) + static_cast<size_t>(rb) * q.nk * G::A_BYTES;
     if constexpr (DMA) {
-      xbase = reinterpret_cast<const char*>(p.x + col0_i * p.ldx);
+      xbase = reinterpret_cast<const char*>(q.x + col0_i * q.ldx);
+      const uint32_t ldx_bytes = static_cast<uint32_t>(q.ldx * sizeof(double));
+      const size_t last_col = q.m - 1;
       const size_t left = last_col - col0_i;                      // columns of the panel behind the tile's first one
       const uint32_t lim = left < static_cast<size_t>(G::BN) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(G::BN);
+      edge_i = left < static_cast<size_t>(G::BN);
+      tail_base0 = false;
 #pragma unroll
       for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
         const uint32_t cc = static_cast<uint32_t>((wid + it * NW) * 8 + (lane >> 3));
@@ -344,7 +425,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // Only the LAST column of the panel needs that: behind every other column lies the next one (or the padding of a
         // strided panel), so the piece can be fetched where it is — its valid element arrives by DMA like any other and
         // fixup_tail() only overwrites the foreign one.
-        if constexpr (TAIL) xsafe[it] = (cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(p.tail_k)) ? X_ROW_BYTES : 0;
+        if constexpr (TAIL) xsafe[it] = (cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(q.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -364,18 +445,19 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto issue_qe = [&]() __attribute__((always_inline)) {
     if constexpr (EPI == EPI_QUAT) {
       if (kc_i == 0) {
+        const ApplyArgs q = reload_kernel_args<ApplyArgs>();
         // 4-byte pieces (256 B per wave instruction): the caller's array ends exactly after the last rod, and a
         // 4-byte granule can be clamped at that end without shifting valid data.
-        const size_t total = (p.m >> 2) * 72;                          // >= 72: at least one rod
+        const size_t total = (q.m >> 2) * 72;                          // >= 72: at least one rod
         const size_t base = (col0_i >> 2) * 72;
-        char* buf = smem + G::LDS_BYTES + (tseq_i % p.side_bufs) * G::SIDE_BYTES;
+        char* buf = smem + G::LDS_BYTES + (tseq_i % q.side_bufs) * G::SIDE_BYTES;
 #pragma unroll
         for (int i = 0; i < (G::QE_BYTES / 256 + NW - 1) / NW; ++i) {
           const int chunk = wid + i * NW;                              // wave-uniform
           if (chunk * 256 < G::QE_BYTES) {
             size_t src = base + chunk * 256 + lane * 4;
             src = src + 4 <= total ? src : total - 4;                  // ragged last tile: re-read valid bytes
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(p.qe) + src),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(q.qe) + src),
                                              (__attribute__((address_space(3))) void*)(buf + chunk * 256), 4, 0, 0);
           }
         }
@@ -383,22 +465,41 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // take it (the first ones carry the extra coefficient piece)
         const int pw = NW - 1 - wid;                                   // wave-uniform
         if (pw * 1024 < G::P1_BYTES && pw * 1024 + lane * 16 < G::P1_BYTES) {
-          const uint32_t rb = tile_i / p.col_tiles;
-          lds_dma16(reinterpret_cast<const char*>(p.leg1 + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
+          const uint32_t rb = tile_i / q.col_tiles;
+          lds_dma16(reinterpret_cast<const char*>(q.leg1 + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
                     buf + G::QE_BYTES + pw * 1024);
         }
         // previous tip values of the tile's columns (m is a multiple of 4, so 16-byte granules never straddle the end)
-        if (p.tips_prev != nullptr && pw == (G::P1_BYTES + 1023) / 1024 && lane * 16 < G::TIPS_BYTES) {
+        if (q.tips_prev != nullptr && pw == (G::P1_BYTES + 1023) / 1024 && lane * 16 < G::TIPS_BYTES) {
           size_t src = col0_i * 8 + lane * 16;
-          src = src + 16 <= p.m * 8 ? src : p.m * 8 - 16;
-          lds_dma16(reinterpret_cast<const char*>(p.tips_prev) + src, buf + G::QE_BYTES + G::P1_BYTES);
+          src = src + 16 <= q.m * 8 ? src : q.m * 8 - 16;
+          lds_dma16(reinterpret_cast<const char*>(q.tips_prev) + src, buf + G::QE_BYTES + G::P1_BYTES);
         }
+      }
+    }
+  };
+  // FOLD on the LDS-DMA path, first stage of a tile: x_base of the columns of this wave's own X pieces, 4 bytes per lane
+  // (entry j = lane >> 1 is the column of lane j of tail_fix_fast()), into this wave's corner of the side buffer of tile
+  // sequence parity.  In FRONT of the stage's own pieces, like the coefficient pieces of EPI_QUAT: the counted waits then
+  // at worst wait for it too.  Read back by the SAME wave after its own vmcnt wait for the tile's last stage.
+  char* const xb_side = smem + (EPI == EPI_QUAT ? G::lds_bytes_quat(static_cast<int>(p.side_bufs)) : G::LDS_BYTES);
+  auto issue_xb = [&]() __attribute__((always_inline)) {
+    if constexpr (XBUF) {
+      if (kc_i == 0) {
+        const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+        const uint32_t j = (static_cast<uint32_t>(lane) >> 1) % (8u * G::X_DMA_PER_WAVE);
+        const size_t col = col0_i + (wid + (j >> 3) * NW) * 8 + (j & 7);
+        const size_t colc = col < q.m ? col : q.m - 1;                       // ragged last tile: any valid address (never read back)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(q.xb) + colc * 8 + (lane & 1) * 4),
+                                         (__attribute__((address_space(3))) void*)(xb_side + (tseq_i & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES),
+                                         4, 0, 0);
       }
     }
   };
   // Fetch the stage under the cursor into ring slot slot_i; advance the cursor.
   auto stage_issue = [&]() __attribute__((always_inline)) {
     issue_qe();
+    issue_xb();
     char* sA = smem + slot_i * G::STAGE_BYTES;
     const char* gA = abase + static_cast<size_t>(kc_i) * G::A_BYTES;
     if (!(ABL & 1) || abl_first) {
@@ -416,12 +517,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
           const int i = wid + it * NW;
           if constexpr (TAIL) {
-            // last chunk: the chunk's offset moves into the lane offset, so that the step back cannot wrap below zero
-            // (kc_i >= 1 there: rows >= 17)
-            const bool last = kc_i + 1 == p.nk;
-            const uint32_t kb = last ? kc_i * static_cast<uint32_t>(X_ROW_BYTES) : 0u;
-            uint32_t voff = xoff[it] + kb - (last ? static_cast<uint32_t>(xsafe[it]) : 0u);
-            lds_dma16_sv(last ? xbase : gX, voff, sX + i * 1024);
+            lds_dma16_sv(tail_base0 ? xbase : gX, xoff[it], sX + i * 1024);     // see cursor_advance
           } else {
             lds_dma16_sv(gX, xoff[it], sX + i * 1024);
           }
@@ -444,7 +540,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // the operator slab, the rest the X panel.  Lets the main loop drop the pieces between MFMA groups.
   auto issue_piece = [&](int idx) __attribute__((always_inline)) {
     char* sA = smem + slot_i * G::STAGE_BYTES;
-    if (idx == 0) issue_qe();
+    if (idx == 0) { issue_qe(); issue_xb(); }
     if (idx < G::A_DMA_PER_WAVE) {
       if (!(ABL & 1) || abl_first) {
         const int i = wid + idx * NW;
@@ -455,10 +551,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         const int it = idx - G::A_DMA_PER_WAVE;
         const int i = wid + it * NW;
         if constexpr (DMA && TAIL) {
-          const bool last = kc_i + 1 == p.nk;                   // see stage_issue
-          const uint32_t kb = last ? kc_i * static_cast<uint32_t>(X_ROW_BYTES) : 0u;
-          uint32_t voff = xoff[it] + kb - (last ? static_cast<uint32_t>(xsafe[it]) : 0u);
-          lds_dma16_sv(last ? xbase : xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, voff, sA + G::A_BYTES + i * 1024);
+          lds_dma16_sv(tail_base0 ? xbase : xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, xoff[it], sA + G::A_BYTES + i * 1024);
         } else {
           lds_dma16_sv(xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, xoff[DMA ? it : 0], sA + G::A_BYTES + i * 1024);
         }
@@ -488,6 +581,18 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       tile_i += gridDim.x;
       if (issued < total_stages) issue_setup();
     }
+    if constexpr (DMA && TAIL) {
+      // The last k chunk of the ONE tile that holds the panel's last column: pieces that reach past the end of the buffer
+      // step back one chunk (xsafe).  The chunk's offset moves into the lane offsets so that the step back cannot wrap below
+      // zero (kc_i >= 1 here: rows >= 17); issue_setup() of the next tile rebuilds xoff[].  Every other stage of a TAIL
+      // build issues exactly like a full-chunk one: no vector-ALU work per piece.
+      if (edge_i && kc_i + 1 == p.nk) {
+#pragma unroll
+        for (int it = 0; it < G::X_DMA_PER_WAVE; ++it)
+          xoff[it] = xoff[it] + kc_i * static_cast<uint32_t>(X_ROW_BYTES) - static_cast<uint32_t>(xsafe[it]);
+        tail_base0 = true;
+      }
+    }
   };
 
   // ---- accumulators and fragment registers -----------------------------------------------------
@@ -498,6 +603,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
 
+  // constant per-lane byte offset of a full tile's Y stores inside the wave's 64 x 64 block: column g, rows 2c, 2c+1
+  // (the host guarantees that 128 columns of Y span < 4 GiB)
+  uint32_t ylane = static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
+  asm volatile("" : "+v"(ylane));
   // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
@@ -511,6 +620,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // once — xq[j][e] for instruction (j, e): element g & 1 of piece 4j + 2e + (g >> 1) of this lane's column — the slot
   // base is ONE add per (j, e) and stage, and the column tile is an immediate offset; an empty asm between the reads of
   // two tiles keeps them apart.
+  int xpp[2] = {0, 0};                                      // paired order: per-lane part of the 16-byte X read of k pair j
+  if constexpr (!ASCK) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xpp[j] = x_off + ((4 * j + g) ^ sig) * 16;
+      asm volatile("" : "+v"(xpp[j]));                       // two registers for the whole kernel, not three VALU instructions per stage
+    }
+  }
   int xq[ASCK ? 2 : 1][2];
   if constexpr (ASCK) {
 #pragma unroll
@@ -551,10 +668,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         }
       }
     } else {
-      const int xpiece = ((4 * j + g) ^ sig) * 16;
+      const char* rd = base + xpp[j];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        b[tn] = *reinterpret_cast<const d2*>(base + x_off + tn * 16 * X_ROW_BYTES + xpiece);
+        b[tn] = *reinterpret_cast<const d2*>(rd + tn * 16 * X_ROW_BYTES);
     }
   };
   // groups [G0, G1) of the k pair held in (a, b); `piece` counts the DMA pieces issued so far in this body
@@ -585,18 +702,18 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
   // Optional by-product: the tip-node value of every column (row 0 of the first row block), the "final
   // integrated state" a multi-GPU run reassembles.  Row 0 sits in acc[0][tn][r] of the lanes with c == 0.
-  auto emit_tips = [&](uint32_t rb, size_t col_base) __attribute__((always_inline)) {
-    if (p.tips == nullptr || rb != 0 || wm != 0) return;      // wave-uniform
+  auto emit_tips = [&](const ApplyArgs& q, uint32_t rb, size_t col_base) __attribute__((always_inline)) {
+    if (q.tips == nullptr || rb != 0 || wm != 0) return;      // wave-uniform
     if (c != 0) return;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const size_t col = col_base + tn * 16 + r * 4;
-        if (col < p.m) {
+        if (col < q.m) {
           double v = acc[0][tn][r];
-          if constexpr (RANK1_EPI) v -= p.w[0] * p.xb[col];
-          p.tips[col] = v;
+          if constexpr (RANK1_EPI) v -= q.w[0] * q.xb[col];
+          q.tips[col] = v;
         }
       }
   };
@@ -605,15 +722,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // Operation order of K and G is that of strain_kernel / quat_rhs_kernel (sri_rod.hip), so the fused iteration is
   // bit-identical to the unfused one.
   auto store_tile_quat = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
-    const uint32_t rb_c = tile / p.col_tiles;
-    const size_t col0_c = static_cast<size_t>(tile % p.col_tiles) * G::BN;
+    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const uint32_t rb_c = tile / q.col_tiles;
+    const size_t col0_c = static_cast<size_t>(tile % q.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
     const size_t col_base4 = col0_c + wn * (TN * 16) + 4 * g;
-    const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
-    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
-    const bool tip_lane = p.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
-    const char* side = smem + G::LDS_BYTES + (tseq_c % p.side_bufs) * G::SIDE_BYTES;
-    const bool monitor = p.partial != nullptr && rb_c == 0 && wm == 0;         // wave-uniform
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows + 1);
+    const bool tip_lane = q.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
+    const char* side = smem + G::LDS_BYTES + (tseq_c % q.side_bufs) * G::SIDE_BYTES;
+    const bool monitor = q.partial != nullptr && rb_c == 0 && wm == 0;         // wave-uniform
     d2 p1[TM / 2];                                               // P1 at this lane's row pairs
 #pragma unroll
     for (int t = 0; t < TM / 2; ++t)
@@ -621,14 +739,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const size_t col = col_base4 + tn * 16;
-      if (!full && col >= p.m) continue;                       // m is a multiple of 4: a rod is in or out as a whole
+      if (!full && col >= q.m) continue;                       // m is a multiple of 4: a rod is in or out as a whole
       const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
       double q9[9], xb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < 9; ++i) q9[i] = qe[i];
       if constexpr (RANK1_EPI) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xb[r] = p.xb[col + r];
+        for (int r = 0; r < 4; ++r) xb[r] = q.xb[col + r];
       }
 #pragma unroll
       for (int t = 0; t < TM / 2; ++t) {
@@ -640,11 +758,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           const double P2 = ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1);   // as strain_kernel (sri_rod.hip)
           double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
           if constexpr (RANK1_EPI) {
-            const double wv = p.w[row + e];
+            const double wv = q.w[row + e];
             qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
           }
           if (tip_lane && t == 0 && e == 0) {
-            p.tips[col + 0] = qw; p.tips[col + 1] = qx; p.tips[col + 2] = qy; p.tips[col + 3] = qz;
+            q.tips[col + 0] = qw; q.tips[col + 1] = qx; q.tips[col + 2] = qy; q.tips[col + 3] = qz;
             if (monitor) {
               const double* old = reinterpret_cast<const double*>(side + G::QE_BYTES + G::P1_BYTES) + (wn * TN + tn) * 16 + 4 * g;
               const double qv[4] = {qw, qx, qy, qz};
@@ -667,30 +785,32 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double* yp = p.y + (col + r) * p.ldy + row;
-          if (full ? (all_rows || row + 1 < p.rows) : (DMA && row + 1 < p.rows)) {
+          double* yp = q.y + (col + r) * q.ldy + row;
+          if (full ? (all_rows || row + 1 < q.rows) : (DMA && row + 1 < q.rows)) {
             *reinterpret_cast<d2*>(yp) = d2{gq[0][r], gq[1][r]};
           } else {
-            if (row < p.rows) yp[0] = gq[0][r];
-            if (!full && row + 1 < p.rows) yp[1] = gq[1][r];
+            if (row < q.rows) yp[0] = gq[0][r];
+            if (!full && row + 1 < q.rows) yp[1] = gq[1][r];
           }
         }
       }
     }
     return full;
   };
+  constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && !RANK1_EPI && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
-    const uint32_t rb_c = tile / p.col_tiles;
+    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const uint32_t rb_c = tile / q.col_tiles;
     // ABL & 128: every tile stores over the FIRST column tile (same instructions, no HBM write traffic)
-    const size_t col0_c = (ABL & 128) ? 0 : static_cast<size_t>(tile % p.col_tiles) * G::BN;
+    const size_t col0_c = (ABL & 128) ? 0 : static_cast<size_t>(tile % q.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
     const size_t col_base = col0_c + wn * (TN * 16) + g;
     // "full": every column of the tile exists and at most the very last row of the row block is missing
     // (rows = 255, 1023, 63, ...).  Then every wave issues at least NSTORE store instructions, which is
     // what the counted waits of the stage stream rely on.
-    const bool all_rows = rb_c * G::BM + G::BM <= p.rows;
-    const bool full = DMA && (col0_c + G::BN <= p.m) && (rb_c * G::BM + G::BM <= p.rows + 1);
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows + 1);
     if ((ABL & 4) != 0 || ((ABL & 32) != 0 && wid < NW / 2) || ((ABL & 64) != 0 && wid >= NW / 2)) {
       // ablation: keep the accumulators live, store nothing
 #pragma unroll
@@ -698,14 +818,49 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
       return false;
-    } else if (full) {
+    } else if (SADDR_STORES && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows + 1)) {
+      // Every column of the tile exists and this WAVE's 64 rows do too, except possibly the very last one (255, 1023, ...
+      // rows): NSTORE 16-byte stores, straight-line, no vector-ALU address arithmetic (store16_sv).  Decided per wave —
+      // the counted waits are per wave as well.
+      const bool odd = rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows + 1;        // wave-uniform: the last row pair is half empty
+      const size_t ldy8 = q.ldy * sizeof(double);
+      char* const ybase = reinterpret_cast<char*>(q.y) + (col0_c + wn * (TN * 16)) * ldy8 +
+                          (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
+      auto emit = [&](auto nt_tag, auto odd_tag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(nt_tag)::value, ODD = decltype(odd_tag)::value;
+        char* cb = ybase;                                                         // uniform: stepped by the scalar ALU
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (tn + r != 0) {
+              cb += 4 * ldy8;                                                       // columns g + 4 (tn * 4 + r)
+              asm volatile("" : "+s"(cb));                                          // one running base, not 16 hoisted (and spilled) ones
+            }
+            static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
+              constexpr int t = decltype(tc)::value;
+              const d2 v = pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]);
+              if constexpr (ODD && t == TM / 2 - 1) {
+                if (c != 15) store16_sv<NT, 256 * t>(cb, ylane, v);
+                else store8_sv<256 * t>(cb, ylane, v[0]);                         // the lane that holds the last row
+              } else {
+                store16_sv<NT, 256 * t>(cb, ylane, v);
+              }
+            });
+          }
+      };
+      if (q.nt_stores != 0) { if (odd) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
+      else { if (odd) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
+      emit_tips(q, rb_c, col_base);
+      return true;
+    } else if (!SADDR_STORES && full) {                     // (with SADDR_STORES every tile that is `full` took the branch above)
       // rank-1 term: this lane's TM row factors once per tile, one x_base value per column (not per store)
       double wv[TM / 2][2];
       if constexpr (RANK1_EPI) {
 #pragma unroll
         for (int t = 0; t < TM / 2; ++t) {
-          wv[t][0] = p.w[row_base + 32 * t];
-          wv[t][1] = p.w[row_base + 32 * t + 1];   // w is zero padded
+          wv[t][0] = q.w[row_base + 32 * t];
+          wv[t][1] = q.w[row_base + 32 * t + 1];   // w is zero padded
         }
       }
       auto emit = [&](auto nt_tag) __attribute__((always_inline)) {
@@ -716,23 +871,23 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           for (int r = 0; r < 4; ++r) {
             const size_t col = col_base + tn * 16 + r * 4;
             double xbv = 0.0;
-            if constexpr (RANK1_EPI) xbv = p.xb[col];
+            if constexpr (RANK1_EPI) xbv = q.xb[col];
 #pragma unroll
             for (int t = 0; t < TM / 2; ++t) {
               const uint32_t row = row_base + 32 * t;
-              double* yp = p.y + col * p.ldy + row;
+              double* yp = q.y + col * q.ldy + row;
               double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
               if constexpr (RANK1_EPI) {
                 v0 -= wv[t][0] * xbv;
                 v1 -= wv[t][1] * xbv;
               }
-              if (all_rows || row + 1 < p.rows) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
+              if (all_rows || row + 1 < q.rows) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
               else *yp = v0;                                                                 // the lane holding the last row
             }
           }
       };
-      if (p.nt_stores != 0) emit(std::true_type{}); else emit(std::false_type{});   // same store count either way
-      emit_tips(rb_c, col_base);
+      if (q.nt_stores != 0) emit(std::true_type{}); else emit(std::false_type{});   // same store count either way
+      emit_tips(q, rb_c, col_base);
       return true;
     } else {
 #pragma unroll
@@ -740,27 +895,27 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t col = col_base + tn * 16 + r * 4;
-          if (col >= p.m) continue;
-          double* ycol = p.y + col * p.ldy;
+          if (col >= q.m) continue;
+          double* ycol = q.y + col * q.ldy;
           double xbv = 0.0;
-          if constexpr (RANK1_EPI) xbv = p.xb[col];
+          if constexpr (RANK1_EPI) xbv = q.xb[col];
 #pragma unroll
           for (int t = 0; t < TM / 2; ++t) {
             const uint32_t row = row_base + 32 * t;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
             if constexpr (RANK1_EPI) {
-              if (row < p.rows) v0 -= p.w[row] * xbv;
-              if (row + 1 < p.rows) v1 -= p.w[row + 1] * xbv;
+              if (row < q.rows) v0 -= q.w[row] * xbv;
+              if (row + 1 < q.rows) v1 -= q.w[row + 1] * xbv;
             }
-            if (DMA && row + 1 < p.rows) {
+            if (DMA && row + 1 < q.rows) {
               *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
             } else {
-              if (row < p.rows) ycol[row] = v0;
-              if (row + 1 < p.rows) ycol[row + 1] = v1;
+              if (row < q.rows) ycol[row] = v0;
+              if (row + 1 < q.rows) ycol[row + 1] = v1;
             }
           }
         }
-      emit_tips(rb_c, col_base);
+      emit_tips(q, rb_c, col_base);
       return false;
     }
   };
@@ -793,6 +948,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   }
 
   uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor (stage whose k pair 0 comes next)
+  uint32_t ct_c = first_tile % p.col_tiles;                // ... its column tile, stepped by
+  const uint32_t ct_step = gridDim.x % p.col_tiles;        //     (tile + gridDim.x) % col_tiles = ct + ct_step (mod col_tiles)
   uint32_t since_store = 99;                               // waits since a FULL tile's NSTORE stores were issued
   // Two fragment register sets: (pa, pb) holds k pair 0 of a stage, (qa, qb) k pair 1.  Every fragment read
   // is issued at least two MFMA groups before its first use, except the early group's read right after a
@@ -808,19 +965,21 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // that no foreign value, possibly NaN/Inf, ever meets the zero padding of the operator).  A handful of
   // elements per column, once per tile, fenced by one extra barrier that both wave groups execute.
   auto fixup_tail = [&](uint32_t slot, uint32_t tile_s) __attribute__((always_inline)) {
+    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const size_t last_col = q.m - 1;
     char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
-    const uint32_t k0 = p.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
+    const uint32_t k0 = q.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
     const uint32_t fixn = BK - k0;                           // elements per column to rewrite
-    const size_t col0_s = static_cast<size_t>(tile_s % p.col_tiles) * G::BN;
-    const uint32_t kbase = (p.nk - 1) * BK;
+    const size_t col0_s = static_cast<size_t>(tile_s % q.col_tiles) * G::BN;
+    const uint32_t kbase = (q.nk - 1) * BK;
     for (uint32_t idx = tid; idx < G::BN * fixn; idx += G::THREADS) {
       const uint32_t cc = idx / fixn, kk = k0 + idx % fixn;
       const size_t col = col0_s + cc;
-      const bool valid = kbase + kk < p.rows;                // a real element of the column (only in the straddling piece)
+      const bool valid = kbase + kk < q.rows;                // a real element of the column (only in the straddling piece)
       if (valid && col < last_col) continue;                 // delivered by the DMA from its own address
       double v = 0.0;
-      if (valid && col == last_col) v = p.x[col * p.ldx + kbase + kk];   // the last column's pieces came from a safe address
-      if constexpr (FOLD) { if (col < p.m && kbase + kk == p.rows) v = p.xb[col]; }
+      if (valid && col == last_col) v = q.x[col * q.ldx + kbase + kk];   // the last column's pieces came from a safe address
+      if constexpr (FOLD) { if (col < q.m && kbase + kk == q.rows) v = q.xb[col]; }
       const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & SWZ);
       *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
     }
@@ -832,15 +991,47 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // wait(s) + barrier(s) for the stage (tile_s, kc_s) in ring slot `slot`.  Ops of this wave younger than
   // stage s's DMA: the DMA of stage s+1, plus a full tile's stores if they were issued after stage s's DMA,
   // i.e. within the last two bodies.
-  auto wait_stage = [&](auto refill_tag, uint32_t slot, uint32_t kc_s, uint32_t tile_s) __attribute__((always_inline)) {
-    if (decltype(refill_tag)::value) {
-      if (since_store < static_cast<uint32_t>(AHEAD)) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<W_STEADY>();
-    } else {
-      wait_stage_and_barrier<0>();                         // tail of the stream: fewer stages in flight
+  // Last k chunk of a tile when rows % 16 != 0, every tile but the one with the panel's last column: the k slots beyond
+  // the last row hold the first elements of the NEXT column (fetched where they lie — in bounds).  Each wave rewrites
+  // them in the columns of its OWN X pieces — zero, or x_base[col] in the slot FOLD uses (from the side buffer its own
+  // DMA filled) — after its own vmcnt wait and BEFORE the stage's barrier: one lane per column, one 8-byte ds_write per
+  // slot (one slot for the N - 1 = 255, 1023, ... rows of the integration operators), no extra barrier.
+  auto tail_fix_fast = [&](uint32_t slot) __attribute__((always_inline)) {
+    const uint32_t tail_k = reload_kernel_args<ApplyArgs>().tail_k;
+    if (lane < 8 * G::X_DMA_PER_WAVE) {
+      const int cc = (wid + (lane >> 3) * NW) * 8 + (lane & 7);
+      char* const colp = smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES;
+      const int sw = (cc >> 1) & SWZ;
+      double v0 = 0.0;
+      if constexpr (XBUF) v0 = *reinterpret_cast<const double*>(xb_side + (tseq_c & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES + lane * 8);
+      for (uint32_t kk = tail_k; kk < static_cast<uint32_t>(BK); ++kk) {
+        *reinterpret_cast<double*>(colp + (((kk >> 1) ^ sw) * 16) + (kk & 1) * 8) = (FOLD && kk == tail_k) ? v0 : 0.0;
+      }
     }
+  };
+  auto wait_stage = [&](auto refill_tag, uint32_t slot, uint32_t kc_s, uint32_t tile_s) __attribute__((always_inline)) {
+    bool fix_fast = false, fix_edge = false;
+    if constexpr (DMA && TAIL) {
+      // (ct_c == last column tile, kept by advance_compute(): a `tile % col_tiles` here is a dozen vector-ALU
+      // instructions — hipcc divides on the float pipe — and was if-converted into EVERY stage: -2.5 %)
+      if (kc_s + 1 == p.nk) {
+        fix_edge = ct_c + 1 == p.col_tiles;
+        fix_fast = !fix_edge;
+      }
+    }
+    if (decltype(refill_tag)::value) {
+      if (since_store < static_cast<uint32_t>(AHEAD)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_BOUNDARY) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_STEADY) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tail of the stream: fewer stages in flight
+    }
+    if constexpr (DMA && TAIL) { if (fix_fast) tail_fix_fast(slot); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (since_store < 99) ++since_store;
     if constexpr (DMA && TAIL) {
-      if (kc_s + 1 == p.nk) fixup_tail(slot, tile_s);
+      if (fix_edge) fixup_tail(slot, tile_s);
     }
     if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
   };
@@ -849,6 +1040,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // behind the awaited stage), 1 if they precede them (only the next wait does).
   auto finish_tile = [&](uint32_t tile, uint32_t since_value) __attribute__((always_inline)) {
     if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
+    if constexpr (SRI_TILE_PRIO != 0 && STAGGER) __builtin_amdgcn_s_setprio(0);   // the stores themselves run at normal priority
     if (store_tile(tile)) {
       since_store = since_value;
     } else {
@@ -868,6 +1060,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if (++kc_c < p.nk) return false;
     kc_c = 0;
     tile_c += gridDim.x;
+    ct_c += ct_step;                                         // column tile of the next tile, without a division
+    ct_c = ct_c >= p.col_tiles ? ct_c - p.col_tiles : ct_c;
     return true;
   };
   auto flush_pieces = [&](int& piece, auto pieces_tag) __attribute__((always_inline)) {
@@ -894,6 +1088,27 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
   };
 
+  // STAMP builds: a cycle-stamped timeline of ONE tile end (the third tile of the workgroup) for one wave of each group:
+  // the body that ends the tile ("state 1": marks 0..5) and the body after it ("state 2": marks 6..11).
+  unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t tl_state = 0;
+  auto tl_begin = [&](bool closes_tile) __attribute__((always_inline)) {
+    if constexpr (STAMP) tl_state = (closes_tile && tseq_c == 2u) ? 1u : (tl_state == 1u ? 2u : 0u);
+  };
+  auto tl_mark = [&](auto ktag) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      constexpr int k = decltype(ktag)::value;
+      if (tl_state != 0u) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (tl_state == 1u) tl[k] = now; else tl[6 + k] = now;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>; using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+
   if (!late) {
     // ---------------- early group (or the whole workgroup when STAGGER is off) ----------------------
     auto body = [&](auto refill_tag) __attribute__((always_inline)) {
@@ -901,7 +1116,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
       seg_start();
+      // The stage that ends in this group's Y stores runs at raised priority: the group takes the MFMA pipe first and
+      // reaches its store burst early, and the partner group then has the whole stage's MFMAs left to cover it.  (With
+      // equal shares both groups run out of MFMAs at the same moment, and the burst is paid in idle cycles at the next barrier.)
+      if constexpr ((SRI_TILE_PRIO & 1) != 0 && STAGGER) { if (kc_c + 1 == p.nk) __builtin_amdgcn_s_setprio(2); }
+      tl_begin(kc_c + 1 == p.nk);
+      tl_mark(K0{});
       wait_stage(refill_tag, slot_c, kc_c, tile_c);
+      tl_mark(K1{});
       seg_mark(0);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
@@ -920,7 +1142,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         cursor_advance();
       }
       const uint32_t done_tile = tile_c;
+      tl_mark(K2{});
       if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); } else seg_mark(3);
+      tl_mark(K3{});
     };
     uint32_t s = 0;
     for (; s < steady_end; ++s) body(std::true_type{});
@@ -955,10 +1179,15 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       using PT = std::integral_constant<bool, PIECES>;
       int piece = 0;
       seg_start();
+      if constexpr ((SRI_TILE_PRIO & 2) != 0 && STAGGER) { if (kc_c + 1 == p.nk) __builtin_amdgcn_s_setprio(2); }   // this body stores (see the early group)
+      tl_begin(kc_c + 1 == p.nk);
+      tl_mark(K0{});
       mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
       const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
       const bool wraps = kc_c + 1 == p.nk;                           // stage s opens the next tile
+      tl_mark(K1{});
       wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + gridDim.x : tile_c);
+      tl_mark(K2{});
       seg_mark(0);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
@@ -967,9 +1196,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       flush_pieces(piece, PT{});
       seg_mark(1);
       const uint32_t done_tile = tile_c;
+      tl_mark(K3{});
       // (Issuing the late group's DMA pieces half a stage later, out of phase with the early group's, was
       // measured: no gain.)  The stores follow this body's pieces in program order.
       if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
+      tl_mark(K4{});
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
       read_pair(slot_c, 1, qa, qb);                                  // (s, 1): used at the top of the next body
       mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
@@ -979,6 +1210,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         cursor_advance();
       }
       seg_mark(3);
+      tl_mark(K5{});
     };
     uint32_t s = 0;
     if (steady_end > 0) first_body(std::true_type{}); else first_body(std::false_type{});
@@ -1021,6 +1253,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int k = 0; k < 6; ++k) q[k] = seg[k];
       q[6] = total_stages;
       q[7] = my_tiles;
+      unsigned long long* t = p.stamps + static_cast<size_t>(gridDim.x) * 24 + (static_cast<size_t>(blockIdx.x) * 2 + (wid ? 1 : 0)) * 12;
+      for (int k = 0; k < 12; ++k) t[k] = tl[k];
     }
   }
 }
@@ -1117,10 +1351,11 @@ static int prepare(int dev) {
   std::lock_guard<std::mutex> lock(prepare_mutex());
   if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
   const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>;
-  constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
+  constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : 0;        // FOLD on the LDS-DMA path: x_base side buffer at the end
+  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
   // the attribute is the most any launch of this kernel may ask for
-  constexpr int lds_max = EPI != EPI_QUAT ? lds : (G::lds_bytes_quat(4) <= 160 * 1024 ? G::lds_bytes_quat(4) : G::lds_bytes_quat(2));
+  constexpr int lds_max = EPI != EPI_QUAT ? lds : (G::lds_bytes_quat(4) + xb <= 160 * 1024 ? G::lds_bytes_quat(4) + xb : G::lds_bytes_quat(2) + xb);
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
@@ -1142,7 +1377,7 @@ static int prepare_geometry(int dev) {
   }
   if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
   if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
-  if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
+  if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
     if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 4>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 4>(dev);
     if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT, 4>(dev);
@@ -1169,7 +1404,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;
   }
-  constexpr int lds = EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES;
+  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + ((DMA && RANK1 && TAIL) ? G::XB_BYTES : 0);
   SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>), dim3(grid), dim3(G::THREADS), lds, stream, args));
   return SRI_OK;
 }
@@ -1193,7 +1428,7 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
       if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
       return SRI_EUNSUPPORTED;                             // register-staged build: rows < 16, one chunk
     }
-    if constexpr (G::lds_bytes_quat(4) <= 160 * 1024) {
+    if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {
       if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
       if (dma) return launch<G, true, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
       return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
@@ -1376,7 +1611,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // the register-staged build.
   const bool dma = h->rows >= 16;
   // the LDS-DMA pieces address a tile as a uniform 64-bit base + a 32-bit lane offset: 128 columns must span < 4 GiB
-  if (dma && (static_cast<unsigned long long>(ldx) * 8ull * 128ull + static_cast<unsigned long long>(h->rows) * 8ull) >= (1ull << 32))
+  if (dma && (static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * 128ull + static_cast<unsigned long long>(h->rows) * 8ull) >= (1ull << 32))
     return SRI_EUNSUPPORTED;
   args.tail_k = h->rows % 16;
   args.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--data", default="rod")
+    ap.add_argument("--ld", type=int, default=0, help="leading dimension of X and Y (default: rows)")
     ap.add_argument("--libs", nargs="+", required=True)
     a = ap.parse_args()
     import torch
@@ -55,14 +56,19 @@ def main():
         variants.append((name, lib, h, r.value))
     rows = variants[0][3]
     X = bench.device_panel(torch, a.n, rows, a.rods, a.data, 0x5EED, dev)
-    Ys = [torch.empty_like(X) for _ in variants]
     M = 4 * a.rods
+    ld = a.ld or rows
+    if ld != rows:                                             # strided panels: ld doubles per column, the tail is NaN
+        Xs = torch.full((M, ld), float("nan"), dtype=torch.float64, device=dev)
+        Xs[:, :rows] = X
+        X = Xs
+    Ys = [torch.empty_like(X) for _ in variants]
     stream = torch.cuda.current_stream().cuda_stream
 
     def run(k, reps):
         name, lib, h, _ = variants[k]
         for _ in range(reps):
-            rc = lib.sri_apply(h, X.data_ptr(), rows, Ys[k].data_ptr(), rows, M, stream)
+            rc = lib.sri_apply(h, X.data_ptr(), ld, Ys[k].data_ptr(), ld, M, stream)
             assert rc == 0
 
     t0 = time.perf_counter()
@@ -80,9 +86,9 @@ def main():
             torch.cuda.synchronize()
             times[v[0]].append(e0.elapsed_time(e1) / a.reps)
     flops = 8.0 * rows * rows * a.rods
-    same = all(torch.equal(Ys[0], y) for y in Ys[1:])
+    same = all(torch.equal(Ys[0][:, :rows], y[:, :rows]) for y in Ys[1:])
     for name, ts in times.items():
-        print(f"{name:>10s}  N={a.n} rods={a.rods}  min {min(ts):.4f} ms  median {statistics.median(ts):.4f} ms  "
+        print(f"{name:>10s}  N={a.n} op={a.operator} ld={ld} rods={a.rods}  min {min(ts):.4f} ms  median {statistics.median(ts):.4f} ms  "
               f"{flops / min(ts) / 1e9:.2f} TF/s (min)  {flops / statistics.median(ts) / 1e9:.2f} TF/s (median)")
     print("outputs bit-identical across variants:", same)
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <random>
+#include <string>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -73,6 +74,7 @@ static void ablate(const char* name, ApplyArgs a, size_t col_tiles, size_t block
 }
 
 int main(int argc, char** argv) {
+  const bool timeline_only = argc > 3 && std::string(argv[3]) == "timeline";
   const uint32_t n = argc > 1 ? atoi(argv[1]) : 256;
   const size_t rods = argc > 2 ? atol(argv[2]) : 65536;
   const size_t M = rods * 4;
@@ -99,7 +101,10 @@ int main(int argc, char** argv) {
   const size_t col_tiles = (M + GeoTall::BN - 1) / GeoTall::BN;
   int tall_per_cu = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&tall_per_cu, apply_kernel<GeoTall, true, false, false, false>, GeoTall::THREADS, GeoTall::LDS_BYTES));
-  const size_t blocks = std::min<size_t>(col_tiles * a.row_blocks, (size_t)tall_per_cu * prop.multiProcessorCount);   // persistent grid
+  size_t blocks = std::min<size_t>(col_tiles * a.row_blocks, (size_t)tall_per_cu * prop.multiProcessorCount);   // persistent grid
+  if (const char* cap = getenv("DIAG_BLOCKS")) {        // DIAG_BLOCKS=32: 32 workgroups on 8 tiles each (the panel shrinks with the grid)
+    blocks = std::min<size_t>(blocks, (size_t)atol(cap));
+  }
   const double flops = 2.0 * n * (double)n * M;
 
   float mn;
@@ -111,11 +116,21 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dX, hx.data(), sizeof(double) * n * M, hipMemcpyHostToDevice));
 
   // STAMP run
-  CK(hipMalloc(&dS, sizeof(unsigned long long) * 24 * blocks));
-  CK(hipMemset(dS, 0, sizeof(unsigned long long) * 24 * blocks));
+  CK(hipMalloc(&dS, sizeof(unsigned long long) * 48 * blocks));
+  CK(hipMemset(dS, 0, sizeof(unsigned long long) * 48 * blocks));
   a.stamps = dS;
-  ms = time_kernel<GeoTall, true, true>(a, col_tiles, 5, &mn);
-  printf("stamped  : mean %.4f ms (min %.4f)\n", ms, mn);
+  // DIAG_ABL selects the ablation of the stamped run whose timeline is printed: 0 = product, 16 = workgroups start (b % 8) / 8
+  // of a tile apart, 128 = every tile stores over the first one (no HBM write traffic), 32 / 64 = one group stores nothing
+  const int diag_abl = getenv("DIAG_ABL") ? atoi(getenv("DIAG_ABL")) : 0;
+  switch (diag_abl) {
+    case 16: ms = time_kernel<GeoTall, true, true, 16>(a, col_tiles, 5, &mn); break;
+    case 512: ms = time_kernel<GeoTall, true, true, 512>(a, col_tiles, 5, &mn); break;
+    case 128: ms = time_kernel<GeoTall, true, true, 128>(a, col_tiles, 5, &mn); break;
+    case 32: ms = time_kernel<GeoTall, true, true, 32>(a, col_tiles, 5, &mn); break;
+    case 64: ms = time_kernel<GeoTall, true, true, 64>(a, col_tiles, 5, &mn); break;
+    default: ms = time_kernel<GeoTall, true, true>(a, col_tiles, 5, &mn); break;
+  }
+  printf("stamped (ablation %d) : mean %.4f ms (min %.4f)\n", diag_abl, ms, mn);
   std::vector<unsigned long long> s(8 * blocks);
   CK(hipMemcpy(s.data(), dS, sizeof(unsigned long long) * 8 * blocks, hipMemcpyDeviceToHost));
   // real-time base
@@ -171,7 +186,31 @@ int main(int argc, char** argv) {
     }
   }
 
+  // ---- timeline of one tile end (third tile of every workgroup), cycles relative to the early wave leaving barrier(S) ----
+  {
+    std::vector<unsigned long long> tlv(48 * blocks);
+    CK(hipMemcpy(tlv.data(), dS, sizeof(unsigned long long) * 48 * blocks, hipMemcpyDeviceToHost));
+    const char* ne[12] = {"S: body top", "S: barrier(S) left", "S: MFMAs done", "S: stores issued+zeroed", "-", "-",
+                          "S+1: body top", "S+1: barrier(S+1) left", "S+1: MFMAs done", "S+1: body end", "-", "-"};
+    const char* nl[12] = {"body top", "group 0 done, at barrier(S+1)", "barrier(S+1) left", "rest of (S,1) done", "stores issued+zeroed", "pair (S+1,0) done",
+                          "next: body top", "next: at barrier(S+2)", "next: barrier(S+2) left", "next: rest done", "next: (no stores)", "next: body end"};
+    for (int grp = 0; grp < 2; ++grp) {
+      printf("%s wave, tile-end timeline (median cycles after the early wave left barrier(S); p10..p90):\n", grp ? "late " : "early");
+      for (int k = 0; k < 12; ++k) {
+        std::vector<double> d;
+        for (size_t b = 0; b < blocks; ++b) {
+          const unsigned long long* te = &tlv[24 * blocks + (b * 2 + 0) * 12];
+          const unsigned long long* tg = &tlv[24 * blocks + (b * 2 + grp) * 12];
+          if (te[1] != 0 && tg[k] != 0) d.push_back((double)((long long)(tg[k] - te[1])));
+        }
+        if (d.empty()) continue;
+        printf("   %-34s %8.0f   (%.0f .. %.0f)\n", grp ? nl[k] : ne[k], med(d), pct(d, .1), pct(d, .9));
+      }
+    }
+  }
+
   // ---- ablations (results wrong by construction; timing + clock only) --------------------------
+  if (timeline_only) { sri_apply_destroy(h); return 0; }
   ablate<0>("none (stamped product kernel)", a, col_tiles, blocks, flops, dS);
   ablate<1>("no A re-fetch (L2->LDS)", a, col_tiles, blocks, flops, dS);
   ablate<2>("no X fetch (HBM->LDS)", a, col_tiles, blocks, flops, dS);
