@@ -611,7 +611,8 @@ def run_rank(args, world_env) -> int:
         if forced in ("paired", "ascending"):
             asc = forced == "ascending"
         limited = args.data == "rod" and which == sri.OP_DN and n >= 1024
-        g = oracle.parity_gate(A, Xh, Yh, n, ascending=asc, cancellation_limited=limited, exact=not args.no_verify)
+        # (--no-verify skips the binary128 product — except where the gate cannot be decided without it)
+        g = oracle.parity_gate(A, Xh, Yh, n, ascending=asc, cancellation_limited=limited, exact=(not args.no_verify) or limited)
         if not args.no_verify and "gpu_vs_binary128" not in g:
             Yx, Yr = oracle.apply_exact(A, Xh), oracle.apply(A, Xh, threads=0)
             nx = float(np.linalg.norm(Yx))

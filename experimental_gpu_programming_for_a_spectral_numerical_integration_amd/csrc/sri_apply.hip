@@ -109,9 +109,6 @@ inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_asc
 #ifndef SRI_STORE_SADDR
 #define SRI_STORE_SADDR 1            // 1: full tiles store through `global_store_dwordx4 v_off, v[..], s[base:base+1] offset:imm` —
 #endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
-#ifndef SRI_TILE_PRIO
-#define SRI_TILE_PRIO 0              // bit 0 / bit 1: the early / late wave group runs the MFMAs in front of its Y stores at raised priority
-#endif
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16; NSTAGE LDS ring slots.
 template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
@@ -173,6 +170,7 @@ struct ApplyArgs {
   uint32_t nk;           // k chunks
   uint32_t row_blocks;
   uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
+  uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel), set by launch()
   uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
   uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
@@ -349,6 +347,15 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     st_r0 = __builtin_amdgcn_s_memrealtime();
   }
 
+#ifndef SRI_WG_PHASE
+#define SRI_WG_PHASE 0               // experiment: the second half of the grid (the second workgroup of every CU) starts half a tile later
+#endif
+  if constexpr (SRI_WG_PHASE != 0 && NW == 4) {
+    if (blockIdx.x >= gridDim.x / 2) {
+      const unsigned steps = p.nk * 4096u / 8128u;
+      for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   if constexpr ((ABL & 512) != 0) {
     // workgroups of ONE XCD (consecutive b / 8) start (b / 8 % 32) / 32 of a tile apart: no two CUs of an XCD end a tile together
     const unsigned steps = ((blockIdx.x >> 3) % 32) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 32 / 8128;
@@ -371,9 +378,24 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int wm = SRI_WAVE_ROW_MAJOR ? wid % G::WM : wid / WN, wn = SRI_WAVE_ROW_MAJOR ? wid / G::WM : wid % WN;
   const int c = lane & 15, g = lane >> 4;
 
-  const uint32_t ntiles = p.row_blocks * p.col_tiles;
-  const uint32_t first_tile = blockIdx.x;      // host guarantees gridDim.x <= ntiles
-  const uint32_t my_tiles = (ntiles - first_tile + gridDim.x - 1) / gridDim.x;
+  // Which tiles this workgroup walks: first_tile, first_tile + tile_step, ... (my_tiles of them; tile = rb * col_tiles + ct).
+  //   order 0: b, b + grid, ...  With the row block slowest, all CUs stream the same slab of the operator at any time (it
+  //            stays in every XCD's L2) — and an operator of several row blocks re-reads the X panel once per row block.
+  //   order 1 (operators of >= 2 row blocks on a full grid; launch() checks the divisibility): the 32 workgroups of an XCD
+  //            (b % 8 = XCD, round-robin dispatch) are grid/8/RB column tiles x ALL RB row blocks, and a workgroup keeps
+  //            its row block: the RB workgroups that share a column tile run on ONE XCD, in step, so its L2 misses the
+  //            X tile once instead of RB times (the operator's RB slabs stream through that L2 instead, each shared by the
+  //            XCD's column tiles).  N = 1024: HBM traffic 2.6 x algorithmic -> see DESIGN.md §4.
+  uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, my_tiles;      // host guarantees gridDim.x <= tiles
+  if (p.tile_order == 1u) {
+    const uint32_t rbs = p.row_blocks, cpx = (gridDim.x >> 3) / rbs;      // column tiles of an XCD per round
+    const uint32_t slot = blockIdx.x >> 3, ct0 = (blockIdx.x & 7u) * cpx + slot / rbs;
+    tile_step = 8u * cpx;
+    first_tile = (slot % rbs) * p.col_tiles + ct0;
+    my_tiles = (p.col_tiles - ct0 + tile_step - 1) / tile_step;           // launch(): col_tiles >= tile_step, so >= 1
+  } else {
+    my_tiles = (p.row_blocks * p.col_tiles - first_tile + gridDim.x - 1) / gridDim.x;
+  }
   const uint32_t total_stages = my_tiles * p.nk;
 
   // ---- issue-side cursor: the (tile, chunk) whose stage is fetched next ------------------------
@@ -578,7 +600,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if (++kc_i == p.nk) {
       kc_i = 0;
       ++tseq_i;
-      tile_i += gridDim.x;
+      tile_i += tile_step;
       if (issued < total_stages) issue_setup();
     }
     if constexpr (DMA && TAIL) {
@@ -949,7 +971,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 
   uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor (stage whose k pair 0 comes next)
   uint32_t ct_c = first_tile % p.col_tiles;                // ... its column tile, stepped by
-  const uint32_t ct_step = gridDim.x % p.col_tiles;        //     (tile + gridDim.x) % col_tiles = ct + ct_step (mod col_tiles)
+  const uint32_t ct_step = tile_step % p.col_tiles;        //     (tile + tile_step) % col_tiles = ct + ct_step (mod col_tiles)
   uint32_t since_store = 99;                               // waits since a FULL tile's NSTORE stores were issued
   // Two fragment register sets: (pa, pb) holds k pair 0 of a stage, (qa, qb) k pair 1.  Every fragment read
   // is issued at least two MFMA groups before its first use, except the early group's read right after a
@@ -1040,7 +1062,6 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // behind the awaited stage), 1 if they precede them (only the next wait does).
   auto finish_tile = [&](uint32_t tile, uint32_t since_value) __attribute__((always_inline)) {
     if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
-    if constexpr (SRI_TILE_PRIO != 0 && STAGGER) __builtin_amdgcn_s_setprio(0);   // the stores themselves run at normal priority
     if (store_tile(tile)) {
       since_store = since_value;
     } else {
@@ -1059,7 +1080,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
     if (++kc_c < p.nk) return false;
     kc_c = 0;
-    tile_c += gridDim.x;
+    tile_c += tile_step;
     ct_c += ct_step;                                         // column tile of the next tile, without a division
     ct_c = ct_c >= p.col_tiles ? ct_c - p.col_tiles : ct_c;
     return true;
@@ -1116,10 +1137,6 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
       using PT = std::integral_constant<bool, PIECES>;
       seg_start();
-      // The stage that ends in this group's Y stores runs at raised priority: the group takes the MFMA pipe first and
-      // reaches its store burst early, and the partner group then has the whole stage's MFMAs left to cover it.  (With
-      // equal shares both groups run out of MFMAs at the same moment, and the burst is paid in idle cycles at the next barrier.)
-      if constexpr ((SRI_TILE_PRIO & 1) != 0 && STAGGER) { if (kc_c + 1 == p.nk) __builtin_amdgcn_s_setprio(2); }
       tl_begin(kc_c + 1 == p.nk);
       tl_mark(K0{});
       wait_stage(refill_tag, slot_c, kc_c, tile_c);
@@ -1179,14 +1196,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       using PT = std::integral_constant<bool, PIECES>;
       int piece = 0;
       seg_start();
-      if constexpr ((SRI_TILE_PRIO & 2) != 0 && STAGGER) { if (kc_c + 1 == p.nk) __builtin_amdgcn_s_setprio(2); }   // this body stores (see the early group)
       tl_begin(kc_c + 1 == p.nk);
       tl_mark(K0{});
       mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
-      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
       const bool wraps = kc_c + 1 == p.nk;                           // stage s opens the next tile
+      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
       tl_mark(K1{});
-      wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + gridDim.x : tile_c);
+      wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + tile_step : tile_c);
       tl_mark(K2{});
       seg_mark(0);
       const uint32_t rslot = slot_i;
@@ -1265,7 +1281,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #ifndef SRI_TALL_WAVES
 #define SRI_TALL_WAVES 8             // experiment knob: 16 = four waves per SIMD with 64x32 wave tiles
 #endif
-#if SRI_TALL_WAVES == 16
+#if SRI_TALL_WAVES == 4
+// BM 256 x BN 64, 4 waves of 64 x 64, TWO ring slots (80 KiB): two INDEPENDENT workgroups per CU — no barrier couples the
+// wave that issues a tile's Y stores to its partner on the SIMD (experiment, see DESIGN.md "tile ends")
+using GeoTall = Geo<4, 1, 4, 4, 2>;
+#elif SRI_TALL_WAVES == 16
 using GeoTall = Geo<4, 4, 4, 2, 3>;   // BM 256 x BN 128, 16 waves (64x32 each), 144 KiB ring, 1 WG/CU
 #else
 using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...)
@@ -1400,6 +1420,10 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   size_t resident = static_cast<size_t>(num_cus) * per_cu;
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
+  // XCD-grouped walk (see the kernel): only where it is well defined — a full grid that splits into 8 XCDs x row blocks,
+  // at least one round of column tiles for everybody — and wanted (SRI_TILE_ORDER=0 keeps the plain walk: A/B, profiles)
+  static const bool order_off = [] { const char* v = std::getenv("SRI_TILE_ORDER"); return v && v[0] == '0'; }();
+  args.tile_order = (!order_off && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
   if (partials != nullptr) {
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;
@@ -1603,6 +1627,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.nk = h->nk;
   args.row_blocks = h->row_blocks;
   args.col_tiles = 0;   // set by launch()
+  args.tile_order = 0;  // set by launch()
   args.stamps = nullptr;
 
   // LDS-DMA (16 bytes per lane) and 16-byte stores work at 8-byte alignment on gfx950 at ~96 % of the aligned

@@ -125,6 +125,9 @@ int main(int argc, char** argv) {
   switch (diag_abl) {
     case 16: ms = time_kernel<GeoTall, true, true, 16>(a, col_tiles, 5, &mn); break;
     case 512: ms = time_kernel<GeoTall, true, true, 512>(a, col_tiles, 5, &mn); break;
+    case 3: ms = time_kernel<GeoTall, true, true, 3>(a, col_tiles, 5, &mn); break;
+    case 1: ms = time_kernel<GeoTall, true, true, 1>(a, col_tiles, 5, &mn); break;
+    case 2: ms = time_kernel<GeoTall, true, true, 2>(a, col_tiles, 5, &mn); break;
     case 128: ms = time_kernel<GeoTall, true, true, 128>(a, col_tiles, 5, &mn); break;
     case 32: ms = time_kernel<GeoTall, true, true, 32>(a, col_tiles, 5, &mn); break;
     case 64: ms = time_kernel<GeoTall, true, true, 64>(a, col_tiles, 5, &mn); break;
