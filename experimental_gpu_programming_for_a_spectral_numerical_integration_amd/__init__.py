@@ -48,6 +48,7 @@ C_ABI = {
     "sri_apply_dim": (_int, [_vp, C.POINTER(_u32)]),
     "sri_apply": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp]),
     "sri_apply_tips": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _vp]),
+    "sri_apply_many": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _sz, _vp]),
     "sri_integrate": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp]),
     "sri_integrate_tips": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
@@ -272,6 +273,30 @@ class SpectralApply:
         return Y
 
     __call__ = apply
+
+    def apply_many(self, Xs, outs=None, stream=None):
+        """``sri_apply_many``: ``Y_i = A @ X_i`` for a list of equally shaped panels in ONE persistent launch.
+
+        Returns the list of outputs.  The device arrays of panel pointers are built here (two small host-to-device
+        copies); a caller that reuses the same panels should keep them and call the C ABI directly."""
+        import torch
+
+        Xs = [self._panel(X, "X") for X in Xs]
+        if not Xs:
+            return []
+        if any(X.shape != Xs[0].shape or X.device != Xs[0].device for X in Xs):
+            raise ValueError("all panels must have the same shape and device")
+        Ys = [torch.empty_like(X) for X in Xs] if outs is None else [self._panel(Y, "out") for Y in outs]
+        if len(Ys) != len(Xs) or any(Y.shape != Xs[0].shape for Y in Ys):
+            raise ValueError("outs must match Xs")
+        dev = Xs[0].device
+        px = torch.tensor([X.data_ptr() for X in Xs], dtype=torch.int64).to(dev)
+        py = torch.tensor([Y.data_ptr() for Y in Ys], dtype=torch.int64).to(dev)
+        M = Xs[0].numel() // self.rows
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _chk(load_library().sri_apply_many(self._h, px.data_ptr(), self.rows, py.data_ptr(), self.rows, M, len(Xs), s), "sri_apply_many")
+        self._keep = (px, py)                                  # alive until the next call: the launch reads them asynchronously
+        return Ys
 
     def integrate(self, B, x_base, out=None, stream=None):
         """``Y = Dnn_inv @ (B - Dn_IN x_base^T)`` (main.cpp:172), operator must be ``OP_DNN_INV``.

@@ -170,6 +170,11 @@ struct ApplyArgs {
   uint32_t nk;           // k chunks
   uint32_t row_blocks;
   uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
+  // sri_apply_many: `panels` > 0 independent panels of m columns each behind DEVICE arrays of device pointers (x, y unused);
+  // tile = (panel * row_blocks + rb) * col_tiles + ct.  Plain apply only.
+  const double* const* xs;
+  double* const* ys;
+  uint32_t panels;
   uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel), set by launch()
   uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
   uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
@@ -269,6 +274,20 @@ __device__ __forceinline__ Args reload_kernel_args() {
   return *base;
 #else
   return Args{};
+#endif
+}
+
+// One pointer out of a device array of pointers, by a SCALAR load (the index is wave-uniform): a vector load here would be
+// one more vmcnt event in a kernel that counts vmcnt itself — and a reason for hipcc to insert waits of its own.
+template <class T>
+__device__ __forceinline__ T* load_uniform_pointer(T* const* array, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T* const* slot = array + index;
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(slot) : "memory");
+  return reinterpret_cast<T*>(v);
+#else
+  return array[index];
 #endif
 }
 
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     first_tile = (slot % rbs) * p.col_tiles + ct0;
     my_tiles = (p.col_tiles - ct0 + tile_step - 1) / tile_step;           // launch(): col_tiles >= tile_step, so >= 1
   } else {
-    my_tiles = (p.row_blocks * p.col_tiles - first_tile + gridDim.x - 1) / gridDim.x;
+    my_tiles = ((p.panels != 0 ? p.panels : 1u) * p.row_blocks * p.col_tiles - first_tile + gridDim.x - 1) / gridDim.x;
   }
   const uint32_t total_stages = my_tiles * p.nk;
 
@@ -423,11 +442,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     // division and the multiplies out of the branch and run them in every stage (it did: if-conversion).
     uint32_t tile_o = tile_i;
     asm volatile("" : "+s"(tile_o) : : "memory");
-    const uint32_t rb = tile_o / q.col_tiles;
+    uint32_t rb = tile_o / q.col_tiles;
     col0_i = static_cast<size_t>(tile_o % q.col_tiles) * G::BN;
+    const double* xp = q.x;
+    if (q.panels != 0) {                                      // sri_apply_many: (panel, row block) = rb / RB, rb % RB
+      xp = load_uniform_pointer(q.xs, rb / q.row_blocks);
+      rb = rb % q.row_blocks;
+    }
     abase = reinterpret_cast<const char*>(q.apack) + static_cast<size_t>(rb) * q.nk * G::A_BYTES;
     if constexpr (DMA) {
-      xbase = reinterpret_cast<const char*>(q.x + col0_i * q.ldx);
+      xbase = reinterpret_cast<const char*>(xp + col0_i * q.ldx);
       const uint32_t ldx_bytes = static_cast<uint32_t>(q.ldx * sizeof(double));
       const size_t last_col = q.m - 1;
       const size_t left = last_col - col0_i;                      // columns of the panel behind the tile's first one
@@ -823,7 +847,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
     const ApplyArgs q = reload_kernel_args<ApplyArgs>();
-    const uint32_t rb_c = tile / q.col_tiles;
+    uint32_t rb_c = tile / q.col_tiles;
+    double* yp_ = q.y;
+    if (q.panels != 0) {                                      // sri_apply_many
+      yp_ = load_uniform_pointer(q.ys, rb_c / q.row_blocks);
+      rb_c = rb_c % q.row_blocks;
+    }
+    double* const ypanel = yp_;
     // ABL & 128: every tile stores over the FIRST column tile (same instructions, no HBM write traffic)
     const size_t col0_c = (ABL & 128) ? 0 : static_cast<size_t>(tile % q.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
@@ -846,7 +876,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // the counted waits are per wave as well.
       const bool odd = rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows + 1;        // wave-uniform: the last row pair is half empty
       const size_t ldy8 = q.ldy * sizeof(double);
-      char* const ybase = reinterpret_cast<char*>(q.y) + (col0_c + wn * (TN * 16)) * ldy8 +
+      char* const ybase = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16)) * ldy8 +
                           (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
       auto emit = [&](auto nt_tag, auto odd_tag) __attribute__((always_inline)) {
         constexpr bool NT = decltype(nt_tag)::value, ODD = decltype(odd_tag)::value;
@@ -897,7 +927,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
             for (int t = 0; t < TM / 2; ++t) {
               const uint32_t row = row_base + 32 * t;
-              double* yp = q.y + col * q.ldy + row;
+              double* yp = ypanel + col * q.ldy + row;
               double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
               if constexpr (RANK1_EPI) {
                 v0 -= wv[t][0] * xbv;
@@ -918,7 +948,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int r = 0; r < 4; ++r) {
           const size_t col = col_base + tn * 16 + r * 4;
           if (col >= q.m) continue;
-          double* ycol = q.y + col * q.ldy;
+          double* ycol = ypanel + col * q.ldy;
           double xbv = 0.0;
           if constexpr (RANK1_EPI) xbv = q.xb[col];
 #pragma unroll
@@ -993,6 +1023,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     const uint32_t k0 = q.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
     const uint32_t fixn = BK - k0;                           // elements per column to rewrite
     const size_t col0_s = static_cast<size_t>(tile_s % q.col_tiles) * G::BN;
+    const double* const xpanel = q.panels != 0 ? load_uniform_pointer(q.xs, tile_s / q.col_tiles / q.row_blocks) : q.x;
     const uint32_t kbase = (q.nk - 1) * BK;
     for (uint32_t idx = tid; idx < G::BN * fixn; idx += G::THREADS) {
       const uint32_t cc = idx / fixn, kk = k0 + idx % fixn;
@@ -1000,7 +1031,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       const bool valid = kbase + kk < q.rows;                // a real element of the column (only in the straddling piece)
       if (valid && col < last_col) continue;                 // delivered by the DMA from its own address
       double v = 0.0;
-      if (valid && col == last_col) v = q.x[col * q.ldx + kbase + kk];   // the last column's pieces came from a safe address
+      if (valid && col == last_col) v = xpanel[col * q.ldx + kbase + kk];   // the last column's pieces came from a safe address
       if constexpr (FOLD) { if (col < q.m && kbase + kk == q.rows) v = q.xb[col]; }
       const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & SWZ);
       *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
@@ -1412,7 +1443,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
                   uint32_t* partials = nullptr) {
   const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_acquire);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
-  const size_t tiles = col_tiles * args.row_blocks;
+  const size_t tiles = col_tiles * args.row_blocks * (args.panels != 0 ? args.panels : 1u);
   if (tiles == 0) return SRI_OK;
   if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
   args.col_tiles = static_cast<uint32_t>(col_tiles);
@@ -1423,7 +1454,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   // XCD-grouped walk (see the kernel): only where it is well defined — a full grid that splits into 8 XCDs x row blocks,
   // at least one round of column tiles for everybody — and wanted (SRI_TILE_ORDER=0 keeps the plain walk: A/B, profiles)
   static const bool order_off = [] { const char* v = std::getenv("SRI_TILE_ORDER"); return v && v[0] == '0'; }();
-  args.tile_order = (!order_off && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
+  args.tile_order = (!order_off && args.panels == 0 && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
   if (partials != nullptr) {
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;
@@ -1588,10 +1619,20 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   return SRI_OK;
 }
 
+struct ManyPanels {
+  const double* const* xs;   // device array of `count` device pointers
+  double* const* ys;
+  size_t count;
+};
+
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
-               hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr, uint32_t* partials = nullptr) {
-  if (h == nullptr || (M > 0 && (dX == nullptr || dY == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
-  if (M == 0) return SRI_OK;
+               hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr, uint32_t* partials = nullptr,
+               const ManyPanels* many = nullptr) {
+  if (h == nullptr || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
+  if (many == nullptr && M > 0 && (dX == nullptr || dY == nullptr)) return SRI_EINVAL;
+  if (many != nullptr && (many->xs == nullptr || many->ys == nullptr || d_xb != nullptr || d_tips != nullptr || quat != nullptr)) return SRI_EINVAL;
+  if (M == 0 || (many != nullptr && many->count == 0)) return SRI_OK;
+  if (many != nullptr && (many->count > 0xffffffffull || h->rows < 16)) return SRI_EUNSUPPORTED;
   const bool rank1 = d_xb != nullptr;
   if (rank1 && h->d_w == nullptr) return SRI_EINVAL;
   if (quat != nullptr && (!rank1 || M % 4 != 0 || quat->qe == nullptr || quat->leg1 == nullptr))
@@ -1600,7 +1641,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
 
-  if (h->d_apack_small != nullptr && !rank1 && quat == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
+  if (h->d_apack_small != nullptr && !rank1 && quat == nullptr && many == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
     h->last_kernel = "sri_apply_mfma_f64<64x64,dma,one-tile-per-workgroup>";
     return small_launch(h->d_apack_small, dX, ldx, dY, ldy, M, d_tips, h->device, h->num_cus, h->max_workgroups, stream);
   }
@@ -1628,6 +1669,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.row_blocks = h->row_blocks;
   args.col_tiles = 0;   // set by launch()
   args.tile_order = 0;  // set by launch()
+  args.xs = many ? many->xs : nullptr;
+  args.ys = many ? many->ys : nullptr;
+  args.panels = many ? static_cast<uint32_t>(many->count) : 0u;
   args.stamps = nullptr;
 
   // LDS-DMA (16 bytes per lane) and 16-byte stores work at 8-byte alignment on gfx950 at ~96 % of the aligned
@@ -1639,7 +1683,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   if (dma && (static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * 128ull + static_cast<unsigned long long>(h->rows) * 8ull) >= (1ull << 32))
     return SRI_EUNSUPPORTED;
   args.tail_k = h->rows % 16;
-  args.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
+  // (many panels: their bases are only known on the device — plain stores)
+  args.nt_stores = (many == nullptr && ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
   h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);
@@ -1720,6 +1765,13 @@ int sri_apply_dim(const sri_apply_t* h, uint32_t* rows) {
 
 int sri_apply(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, void* hip_stream) {
   return sri::run(h, dX, ldx, dY, ldy, M, nullptr, static_cast<hipStream_t>(hip_stream));
+}
+
+int sri_apply_many(sri_apply_t* h, const double* const* dXs, size_t ldx, double* const* dYs, size_t ldy, size_t M, size_t count,
+                   void* hip_stream) {
+  if (h == nullptr) return SRI_EINVAL;
+  const sri::ManyPanels many{dXs, dYs, count};
+  return sri::run(h, nullptr, ldx, nullptr, ldy, M, nullptr, static_cast<hipStream_t>(hip_stream), nullptr, nullptr, nullptr, &many);
 }
 
 int sri_apply_tips(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, double* d_tips,

@@ -117,6 +117,14 @@ int sri_apply_dim(const sri_apply_t *h, uint32_t *rows);
 int sri_apply(sri_apply_t *h, const double *dX, size_t ldx, double *dY, size_t ldy, size_t M,
               void *hip_stream);
 
+/* `count` INDEPENDENT panels in ONE persistent launch: Y_i = A * X_i, i < count, every panel rows x M with the same
+ * M, ldx, ldy.  dXs, dYs: DEVICE arrays of `count` device pointers (as in batched BLAS).  A caller whose batches arrive as
+ * many small panels — BASELINE config 2 is 4 096 rods: 16.8 MB, a 5 us kernel of which 2.9 us are the launch floor —
+ * pays the launch once and streams at the rate of one large panel.  Results are bit-identical to `count` sri_apply calls.
+ * Operators of at least 16 rows; plain apply only (no tips, no initial-value term). */
+int sri_apply_many(sri_apply_t *h, const double *const *dXs, size_t ldx, double *const *dYs, size_t ldy, size_t M,
+                   size_t count, void *hip_stream);
+
 /* sri_apply that additionally writes the tip-node value of every column, d_tips[j] = Y[0][j]
  * (node 0 is the rod tip X = L: chebyshev_differentiation.h:26), M device doubles.  This is the "final
  * integrated state" a multi-GPU run all-gathers; emitted by the kernel's epilogue at no extra traffic. */

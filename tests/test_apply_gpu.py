@@ -436,3 +436,40 @@ def test_small_batch_kernel_is_graph_capturable(sri):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(Y, ref)
+
+
+# ---- sri_apply_many: many small independent panels in one persistent launch ------------------------------------------
+@pytest.mark.parametrize("n,which,M,count", [
+    (64, 0, 16384, 32),      # BASELINE config 2's panel (4 096 rods), 32 of them: what the entry point exists for
+    (64, 1, 1000, 5),        # 63 rows: tail chunk, ragged last tile and the last-column fix-up in EVERY panel
+    (256, 1, 777, 3),        # the reference's literal product, three ragged panels
+    (256, 0, 4096, 4),
+    (1024, 0, 300, 2),       # four row blocks
+    (16, 0, 8, 7),
+])
+def test_apply_many_is_bit_identical_to_single_applies(sri, n, which, M, count):
+    import torch
+
+    op = sri.SpectralApply(n, which)
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + count)
+    Xs = [torch.rand((M, op.rows), dtype=torch.float64, device="cuda", generator=g) * 2 - 1 for _ in range(count)]
+    singles = [op.apply(X) for X in Xs]
+    outs = [torch.full_like(X, float("nan")) for X in Xs]
+    Ys = op.apply_many(Xs, outs=outs)
+    torch.cuda.synchronize()
+    assert "dma" in op.last_kernel                      # the general streaming kernel, whatever the panel size
+    for i, (Y, ref) in enumerate(zip(Ys, singles)):
+        assert torch.equal(Y, ref), (n, which, M, count, i)
+
+
+def test_apply_many_rejects_what_it_cannot_do(sri):
+    import torch
+
+    op = sri.SpectralApply(8, 0)                        # fewer than 16 rows: register-staged build only
+    X = torch.zeros((4, 8), dtype=torch.float64, device="cuda")
+    with pytest.raises(sri.SriError):
+        op.apply_many([X, X.clone()])
+    op = sri.SpectralApply(64, 0)
+    assert op.apply_many([]) == []
+    with pytest.raises(ValueError):
+        op.apply_many([torch.zeros((4, 64), dtype=torch.float64, device="cuda"), torch.zeros((8, 64), dtype=torch.float64, device="cuda")])
