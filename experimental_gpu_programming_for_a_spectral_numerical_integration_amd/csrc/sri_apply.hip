@@ -1868,20 +1868,68 @@ struct HostPipe {
   }
 };
 
-// Page-locks [ptr, ptr + bytes) for the lifetime of the object; a no-op when the range is already registered (by the
-// caller, or because X and Y overlap) or cannot be (then the copies fall back to HIP's pageable path), and for small
-// buffers: those share heap pages with their neighbours (two registrations of one page do not nest) and gain nothing.
-struct PinnedRange {
+// Page-locks [ptr, ptr + bytes) for the lifetime of the object — through a process-wide registry, because registrations
+// are page-granular and do not nest: two handles (one host thread per GPU is the documented sharding) working on adjacent
+// column slabs of ONE host buffer share a boundary page, or share a read-only X outright, and the call that finishes
+// first must not unregister pages the other call's asynchronous copies still use.  The registry keeps the page-aligned
+// ranges THIS library registered, with reference counts: a request that lies inside a registered range shares it; one
+// that merely overlaps a registered range, or a range the caller (or anyone else) registered, or that cannot be locked,
+// is not pinned at all — the copies then take HIP's pageable path: slower, same stream program, same result.  Small
+// buffers are not pinned either (they share heap pages with their neighbours and gain nothing).
+class PinRegistry {
+ public:
+  static PinRegistry& instance() {
+    static PinRegistry r;
+    return r;
+  }
+  // returns an id > 0 to pass to release(), or 0 if the range is not pinned by this library
+  size_t acquire(const void* p, size_t bytes) {
+    if (p == nullptr || bytes < kMinBytes) return 0;
+    const uintptr_t page = 4096;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (Entry& e : entries_) {
+      if (lo >= e.lo && hi <= e.hi) { ++e.refs; return e.id; }          // inside a range we hold: share it
+      if (lo < e.hi && e.lo < hi) return 0;                             // partial overlap: cannot be registered twice
+    }
+    if (hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();                                          // the caller's own registration, or not lockable
+      return 0;
+    }
+    try {
+      entries_.push_back(Entry{lo, hi, 1, ++next_id_});
+    } catch (const std::bad_alloc&) {
+      (void)hipHostUnregister(reinterpret_cast<void*>(lo));
+      return 0;
+    }
+    return next_id_;
+  }
+  void release(size_t id) {
+    if (id == 0) return;
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (size_t i = 0; i < entries_.size(); ++i) {
+      if (entries_[i].id != id) continue;
+      if (--entries_[i].refs == 0) {
+        if (hipHostUnregister(reinterpret_cast<void*>(entries_[i].lo)) != hipSuccess) (void)hipGetLastError();   // never leave an error for the next launch check
+        entries_.erase(entries_.begin() + static_cast<std::ptrdiff_t>(i));
+      }
+      return;
+    }
+  }
   static constexpr size_t kMinBytes = size_t(1) << 20;
-  void* ptr = nullptr;
-  PinnedRange(const void* p, size_t bytes) {
-    if (p == nullptr || bytes < kMinBytes) return;
-    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void*>(p);
-    else (void)hipGetLastError();
-  }
-  ~PinnedRange() {
-    if (ptr && hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();   // never leave an error for the next launch check
-  }
+
+ private:
+  struct Entry { uintptr_t lo, hi; int refs; size_t id; };
+  std::mutex mutex_;
+  std::vector<Entry> entries_;
+  size_t next_id_ = 0;
+};
+
+struct PinnedRange {
+  size_t id = 0;
+  PinnedRange(const void* p, size_t bytes) : id(PinRegistry::instance().acquire(p, bytes)) {}
+  ~PinnedRange() { PinRegistry::instance().release(id); }
   PinnedRange(const PinnedRange&) = delete;
   PinnedRange& operator=(const PinnedRange&) = delete;
 };

@@ -15,9 +15,24 @@
 #include <new>
 #include <vector>
 
-#include <rccl/rccl.h>
-
 #include "sri_internal.h"
+
+// RCCL is bound at run time, so only its TYPES are needed at compile time.  A ROCm installation without the RCCL
+// development headers must still be able to build libsri_hip.so — the single-GPU apply does not need them: the few
+// declarations used here are then made locally (ABI of rccl.h, stable since NCCL 2.x).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+}
+#endif
 
 namespace {
 
@@ -209,9 +224,13 @@ int sri_allgather_panel(sri_comm_t* h, const double* dY_local, size_t rows, size
                         const size_t* columns_per_rank, void* hip_stream) {
   if (!h || rows == 0) return SRI_EINVAL;
   if (!columns_per_rank) return allgather_doubles(h, dY_local, rows * columns_local, dY_all, nullptr, hip_stream);
-  std::vector<size_t> counts(static_cast<size_t>(h->world));
-  for (int i = 0; i < h->world; ++i) counts[static_cast<size_t>(i)] = rows * columns_per_rank[i];
-  return allgather_doubles(h, dY_local, rows * columns_local, dY_all, counts.data(), hip_stream);
+  try {                                                           // nothing may throw across the C ABI
+    std::vector<size_t> counts(static_cast<size_t>(h->world));
+    for (int i = 0; i < h->world; ++i) counts[static_cast<size_t>(i)] = rows * columns_per_rank[i];
+    return allgather_doubles(h, dY_local, rows * columns_local, dY_all, counts.data(), hip_stream);
+  } catch (const std::bad_alloc&) {
+    return SRI_ENOMEM;
+  }
 }
 
 int sri_last_rccl_error(void) { return g_last_rccl; }

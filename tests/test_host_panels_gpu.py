@@ -133,3 +133,42 @@ def test_a_failed_hip_call_of_the_caller_is_not_reported_as_a_failed_launch(sri)
     torch.cuda.synchronize()
     assert torch.equal(Ys, want[0]) and torch.equal(Yl, want[1]) and torch.equal(Yi, want[2])
     assert np.isfinite(host).all()
+
+
+def test_two_threads_on_adjacent_slabs_and_a_shared_input(sri):
+    """The documented sharding — one host thread and one handle per slab — on ONE host allocation: the slabs are adjacent
+    (they share a boundary page: 255-row columns are 2 040 bytes), and a second pair of threads reads the SAME input.
+    Page-locking is page-granular and does not nest, so the library keeps a reference-counted registry of what it pinned;
+    a call that finishes early must not unlock pages another call still copies from.  Repeated, against the device path."""
+    import threading
+
+    n, which, M = 256, 1, 12_001                                   # 255 rows: nothing is page aligned
+    ops = [sri.SpectralApply(n, which) for _ in range(4)]
+    rows = ops[0].rows
+    X = uniform_panel(rows, 2 * M, seed=11)                         # one allocation, two slabs of M columns
+    Y = np.asfortranarray(np.full((rows, 2 * M), np.nan))
+    Z = [np.asfortranarray(np.full((rows, M), np.nan)) for _ in range(2)]
+    ref = _device_apply(ops[0], X)
+    errors = []
+
+    def work(op, xin, yout):
+        try:
+            for _ in range(3):
+                yout[...] = np.nan
+                op.apply_host(xin, out=yout)
+                if np.isnan(yout).any():
+                    errors.append("NaN left in the output")
+        except Exception as e:                                      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(ops[0], X[:, :M], Y[:, :M])),
+               threading.Thread(target=work, args=(ops[1], X[:, M:], Y[:, M:])),
+               threading.Thread(target=work, args=(ops[2], X[:, :M], Z[0])),      # the same input slab as thread 0, read-only
+               threading.Thread(target=work, args=(ops[3], X[:, :M], Z[1]))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert np.array_equal(Y, ref)
+    assert np.array_equal(Z[0], ref[:, :M]) and np.array_equal(Z[1], ref[:, :M])
