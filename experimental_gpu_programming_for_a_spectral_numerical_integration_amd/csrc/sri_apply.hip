@@ -265,6 +265,14 @@ __device__ __forceinline__ void keep_live(T& v) {
 // at kernel entry.  The tile-boundary code (first stage of a tile, Y stores, tail fix-up) takes its ~25 argument words
 // this way: kept resident they pushed the stage loop past the 102 scalar registers of a wave, and every spilled word
 // is a v_readlane / v_writelane — vector-ALU instructions, i.e. MFMA time — in the middle of the MFMA stream.
+#ifndef SRI_RELOAD_ARGS
+#define SRI_RELOAD_ARGS 1            // A/B knob: 0 = keep the argument block resident in scalar registers (spills into the MFMA stream)
+#endif
+#if SRI_RELOAD_ARGS
+#define SRI_ARGS_HERE reload_kernel_args<ApplyArgs>()
+#else
+#define SRI_ARGS_HERE p
+#endif
 struct ApplyArgs;
 template <class Args>
 __device__ __forceinline__ Args reload_kernel_args() {
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   double tip_update = 0.0;   // EPI_QUAT monitor: largest |tip - previous tip| this lane has seen over all its tiles
   size_t col0_i = 0;
   auto issue_setup = [&]() __attribute__((always_inline)) {
-    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const ApplyArgs q = SRI_ARGS_HERE;
     // Once per tile.  Everything below hangs on the opaque copy of the tile index, so that hipcc cannot hoist the
     // division and the multiplies out of the branch and run them in every stage (it did: if-conversion).
     uint32_t tile_o = tile_i;
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     uint32_t rb = tile_o / q.col_tiles;
     col0_i = static_cast<size_t>(tile_o % q.col_tiles) * G::BN;
     const double* xp = q.x;
-    if (q.panels != 0) {                                      // sri_apply_many: (panel, row block) = rb / RB, rb % RB
+    if (q.panels != 0) {                  // sri_apply_many: (panel, row block) = rb / RB, rb % RB
       xp = load_uniform_pointer(q.xs, rb / q.row_blocks);
       rb = rb % q.row_blocks;
     }
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto issue_qe = [&]() __attribute__((always_inline)) {
     if constexpr (EPI == EPI_QUAT) {
       if (kc_i == 0) {
-        const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+        const ApplyArgs q = SRI_ARGS_HERE;
         // 4-byte pieces (256 B per wave instruction): the caller's array ends exactly after the last rod, and a
         // 4-byte granule can be clamped at that end without shifting valid data.
         const size_t total = (q.m >> 2) * 72;                          // >= 72: at least one rod
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   auto issue_xb = [&]() __attribute__((always_inline)) {
     if constexpr (XBUF) {
       if (kc_i == 0) {
-        const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+        const ApplyArgs q = SRI_ARGS_HERE;
         const uint32_t j = (static_cast<uint32_t>(lane) >> 1) % (8u * G::X_DMA_PER_WAVE);
         const size_t col = col0_i + (wid + (j >> 3) * NW) * 8 + (j & 7);
         const size_t colc = col < q.m ? col : q.m - 1;                       // ragged last tile: any valid address (never read back)
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // Operation order of K and G is that of strain_kernel / quat_rhs_kernel (sri_rod.hip), so the fused iteration is
   // bit-identical to the unfused one.
   auto store_tile_quat = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
-    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const ApplyArgs q = SRI_ARGS_HERE;
     const uint32_t rb_c = tile / q.col_tiles;
     const size_t col0_c = static_cast<size_t>(tile % q.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
@@ -846,10 +854,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && !RANK1_EPI && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
-    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const ApplyArgs q = SRI_ARGS_HERE;
     uint32_t rb_c = tile / q.col_tiles;
     double* yp_ = q.y;
-    if (q.panels != 0) {                                      // sri_apply_many
+    if (q.panels != 0) {                  // sri_apply_many
       yp_ = load_uniform_pointer(q.ys, rb_c / q.row_blocks);
       rb_c = rb_c % q.row_blocks;
     }
@@ -1017,7 +1025,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // that no foreign value, possibly NaN/Inf, ever meets the zero padding of the operator).  A handful of
   // elements per column, once per tile, fenced by one extra barrier that both wave groups execute.
   auto fixup_tail = [&](uint32_t slot, uint32_t tile_s) __attribute__((always_inline)) {
-    const ApplyArgs q = reload_kernel_args<ApplyArgs>();
+    const ApplyArgs q = SRI_ARGS_HERE;
     const size_t last_col = q.m - 1;
     char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
     const uint32_t k0 = q.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // DMA filled) — after its own vmcnt wait and BEFORE the stage's barrier: one lane per column, one 8-byte ds_write per
   // slot (one slot for the N - 1 = 255, 1023, ... rows of the integration operators), no extra barrier.
   auto tail_fix_fast = [&](uint32_t slot) __attribute__((always_inline)) {
-    const uint32_t tail_k = reload_kernel_args<ApplyArgs>().tail_k;
+    const uint32_t tail_k = SRI_ARGS_HERE.tail_k;
     if (lane < 8 * G::X_DMA_PER_WAVE) {
       const int cc = (wid + (lane >> 3) * NW) * 8 + (lane & 7);
       char* const colp = smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES;
@@ -1072,16 +1080,33 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         fix_fast = !fix_edge;
       }
     }
-    if (decltype(refill_tag)::value) {
-      if (since_store < static_cast<uint32_t>(AHEAD)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_BOUNDARY) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_STEADY) : "memory");
+    // One fused `s_waitcnt vmcnt(N) lgkmcnt(0)` in front of the barrier wherever nothing has to happen between the two
+    // waits: splitting it into two instructions measured 0.9 % slower on the headline shape (profiles/r03_ab_wait_split.log).
+    auto fused = [&]() __attribute__((always_inline)) {
+      if (decltype(refill_tag)::value) {
+        if (since_store < static_cast<uint32_t>(AHEAD)) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<W_STEADY>();
+      } else {
+        wait_stage_and_barrier<0>();                       // tail of the stream: fewer stages in flight
+      }
+    };
+    if constexpr (DMA && TAIL) {
+      if (fix_fast) {
+        if (decltype(refill_tag)::value) {
+          if (since_store < static_cast<uint32_t>(AHEAD)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_BOUNDARY) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_STEADY) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        tail_fix_fast(slot);                                // this wave's own pieces have landed: rewrite its columns' tail slots
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        fused();
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tail of the stream: fewer stages in flight
+      fused();
     }
-    if constexpr (DMA && TAIL) { if (fix_fast) tail_fix_fast(slot); }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     if (since_store < 99) ++since_store;
     if constexpr (DMA && TAIL) {
       if (fix_edge) fixup_tail(slot, tile_s);
@@ -1886,21 +1911,23 @@ class PinRegistry {
   size_t acquire(const void* p, size_t bytes) {
     if (p == nullptr || bytes < kMinBytes) return 0;
     const uintptr_t page = 4096;
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
-    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+    const uintptr_t plo = lo & ~(page - 1), phi = (hi + page - 1) & ~(page - 1);       // the pages the range touches
     std::lock_guard<std::mutex> lock(mutex_);
     for (Entry& e : entries_) {
       if (lo >= e.lo && hi <= e.hi) { ++e.refs; return e.id; }          // inside a range we hold: share it
-      if (lo < e.hi && e.lo < hi) return 0;                             // partial overlap: cannot be registered twice
+      if (plo < e.phi && e.plo < phi) return 0;                         // shares a PAGE with one: cannot be locked twice
     }
-    if (hipHostRegister(reinterpret_cast<void*>(lo), hi - lo, hipHostRegisterDefault) != hipSuccess) {
+    // the registration itself is the exact range (HIP looks a pointer up by containment: a neighbour that merely shares
+    // our first or last page stays "pageable" for it, as it must)
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
       (void)hipGetLastError();                                          // the caller's own registration, or not lockable
       return 0;
     }
     try {
-      entries_.push_back(Entry{lo, hi, 1, ++next_id_});
+      entries_.push_back(Entry{lo, hi, plo, phi, 1, ++next_id_});
     } catch (const std::bad_alloc&) {
-      (void)hipHostUnregister(reinterpret_cast<void*>(lo));
+      (void)hipHostUnregister(const_cast<void*>(p));
       return 0;
     }
     return next_id_;
@@ -1920,7 +1947,7 @@ class PinRegistry {
   static constexpr size_t kMinBytes = size_t(1) << 20;
 
  private:
-  struct Entry { uintptr_t lo, hi; int refs; size_t id; };
+  struct Entry { uintptr_t lo, hi, plo, phi; int refs; size_t id; };
   std::mutex mutex_;
   std::vector<Entry> entries_;
   size_t next_id_ = 0;
