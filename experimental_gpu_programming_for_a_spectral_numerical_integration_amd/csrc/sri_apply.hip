@@ -165,6 +165,16 @@ struct ApplyArgs {
   const double* tips_prev;   // EPI_QUAT, optional: tip values of the previous iterate, and
   double* partial;           //   partial[block * WN + wn] = this wave column's largest |tip - previous tip| (NaN if any)
   const unsigned long long* stop;   // optional: the launch does nothing if *stop != 0 (device-driven fixed-point loops)
+  // optional loop control IN the launch (device-driven fixed-point loops without a control kernel): before anything else every
+  // workgroup folds the `fold_n` partial maxima the PREVIOUS launch left in `fold` into one value u; if u <= fold_tol the
+  // loop has converged (state[0] = 1), else if `iteration` (= completed iterations) >= fold_max_iter the budget is spent
+  // (state[0] = 2); workgroup 0 records {stop, iteration, bits(u)} in `state` and the whole grid returns.
+  const double* fold;
+  uint32_t fold_n;
+  uint32_t iteration;
+  double fold_tol;
+  unsigned long long fold_max_iter;
+  unsigned long long* state;
   size_t ldx, ldy, m;    // m = number of columns
   uint32_t rows;         // valid rows of A (= valid k)
   uint32_t nk;           // k chunks
@@ -396,6 +406,36 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   const int tid = threadIdx.x;
   if constexpr (EPI == EPI_QUAT) {
     if (p.stop != nullptr && *p.stop != 0ull) return;          // uniform over the grid: the loop has already converged
+    if (p.state != nullptr && p.fold_n != 0u) {
+      // The loop control that used to be a one-block kernel after every step: the step itself, at its start, folds what the
+      // previous step left.  Every workgroup reads the same few hundred values in the same order, so all of them take the
+      // same decision without talking to each other (same-address atomics from 8 XCDs cost ~200 ns each).  NaN is
+      // "not converged": the loop then runs to its budget.
+      double local = 0.0;
+      for (uint32_t i = tid; i < p.fold_n; i += G::THREADS) {
+        const double d = p.fold[i];
+        local = (d > local || d != d) ? d : local;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double other = __shfl_xor(local, off);
+        local = (other > local || other != other) ? other : local;
+      }
+      double* const wave_max = reinterpret_cast<double*>(smem);               // nothing is in flight yet: the ring is free
+      if ((tid & 63) == 0) wave_max[tid >> 6] = local;
+      __syncthreads();
+      local = wave_max[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) local = (wave_max[w] > local || wave_max[w] != wave_max[w]) ? wave_max[w] : local;
+      __syncthreads();                                                        // the ring may be written from here on
+      const unsigned long long verdict = local <= p.fold_tol ? 1ull : (p.iteration >= p.fold_max_iter ? 2ull : 0ull);
+      if (blockIdx.x == 0 && tid == 0) {
+        p.state[1] = p.iteration;
+        p.state[2] = static_cast<unsigned long long>(__double_as_longlong(local));
+        if (verdict != 0ull) p.state[0] = verdict;
+      }
+      if (verdict != 0ull) return;
+    }
   }
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1684,6 +1724,13 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.tips_prev = quat ? quat->tips_prev : nullptr;
   args.partial = quat ? quat->partial : nullptr;
   args.stop = quat ? quat->stop : nullptr;
+  args.fold = quat ? quat->fold : nullptr;
+  args.fold_n = quat ? quat->fold_n : 0u;
+  args.iteration = quat ? quat->iteration : 0u;
+  args.fold_tol = quat ? quat->fold_tol : 0.0;
+  args.fold_max_iter = quat ? quat->fold_max_iter : 0ull;
+  args.state = quat ? quat->state : nullptr;
+  if (quat != nullptr && quat->state != nullptr && quat->fold_n != 0u && quat->fold == nullptr) return SRI_EINVAL;
   if (quat != nullptr && (quat->partial != nullptr) != (quat->tips_prev != nullptr)) return SRI_EINVAL;
   if (quat != nullptr && quat->partial != nullptr && d_tips == nullptr) return SRI_EINVAL;
   args.ldx = ldx;

@@ -37,6 +37,15 @@ struct QuatEpilogue {
   // optional: device word; the launch is a no-op when it is non-zero (lets a fixed-point loop be enqueued ahead of its
   // own convergence test)
   const unsigned long long* stop = nullptr;
+  // optional: loop control inside the launch — before it does anything, the launch folds the `fold_n` partial maxima of the
+  // PREVIOUS step (`fold`), and if their maximum is <= fold_tol (converged: state[0] = 1) or `iteration` completed steps
+  // have reached fold_max_iter (state[0] = 2) it records {stop, iteration, bits(maximum)} in `state` and returns
+  const double* fold = nullptr;
+  uint32_t fold_n = 0;
+  uint32_t iteration = 0;
+  double fold_tol = 0.0;
+  unsigned long long fold_max_iter = 0;
+  unsigned long long* state = nullptr;
 };
 // `partials`: in = capacity of quat.partial (entries), out = entries written by this launch.
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,

@@ -264,34 +264,6 @@ __global__ __launch_bounds__(256) void prolong_rhs_kernel(uint32_t m, size_t rod
   }
 }
 
-// Loop control of the device-driven Picard iteration; one block.  state = {stop, iterations, bits(update), -}.
-// Runs after every fused step: unless the loop has stopped, folds the step's partial maxima into `update`, counts the
-// iteration and raises stop = 1 (update <= tol) or 2 (iteration budget spent).  NaN compares false: runs to the budget.
-__global__ void picard_control_kernel(const double* __restrict__ partial, uint32_t n, double tol, unsigned long long max_iter,
-                                      unsigned long long* state) {
-  if (state[0] != 0ull) return;
-  __shared__ double wave_max[4];
-  double local = 0.0;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const double d = partial[i];
-    local = d > local || d != d ? d : local;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double other = __shfl_xor(local, off);
-    local = (other > local || other != other) ? other : local;
-  }
-  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) local = (wave_max[w] > local || wave_max[w] != wave_max[w]) ? wave_max[w] : local;
-    const unsigned long long it = state[1] + 1ull;
-    state[1] = it;
-    state[2] = static_cast<unsigned long long>(__double_as_longlong(local));
-    if (local <= tol) state[0] = 1ull;
-    else if (it >= max_iter) state[0] = 2ull;
-  }
-}
-
 }  // namespace sri
 
 // ------------------------------------------------------------------------------------------------
@@ -392,7 +364,7 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
       hipMemcpy(h->d_leg, leg.data(), sizeof(double) * leg.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess ||
       (h->cap_partial = sri::max_partials(integ)) == 0 ||
-      hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial) != hipSuccess ||
+      hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial * 2) != hipSuccess ||     // two steps' worth: step k folds step k-1's
       hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[0], hipEventDisableTiming) != hipSuccess ||
@@ -594,11 +566,13 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // Fixed-point loop, one fused launch per iteration:  G^{k+1} = 1/2 A(K) Q^{k+1},  Q^{k+1} = Dnn^-1 G^k - w q0^T.
   // DEVICE-DRIVEN: convergence is decided on the GPU.  Every fused step leaves the largest change of the TIP node of
   // any column of Q in a small array (the Picard error of Q' = 1/2 A(K) Q grows with arc length, so the tip — node 0,
-  // X = 1 — converges last; the apply emits and compares the tip row in its epilogue at no extra traffic), a one-block
-  // control kernel folds it, counts the iteration and raises a stop word, and every later fused launch returns at once
-  // when that word is set.  The host therefore enqueues whole chunks of iterations without waiting, keeps two chunks in
-  // flight (8 iterations each; 4 after a predicted start), and only reads back the 32-byte loop state per chunk: no host round trip sits between two iterations, and
-  // the launches enqueued past convergence cost a few microseconds each instead of an iteration.
+  // X = 1 — converges last; the apply emits and compares the tip row in its epilogue at no extra traffic).  The NEXT step,
+  // before it does anything else, folds that array — every workgroup for itself, all to the same value — counts the
+  // iteration and, if the update is <= tol or the budget is spent, raises the stop word and returns; every later launch
+  // returns at once when the word is set.  (Round 2 ran a one-block control kernel between the steps: 12-46 launches of
+  // 5.5 us per solve.)  The host therefore enqueues whole chunks of iterations without waiting, keeps two chunks in
+  // flight (8 iterations each; 2 after a predicted start), and only reads back the 32-byte loop state per chunk: no host
+  // round trip sits between two iterations, and the launches enqueued past convergence cost a few microseconds each.
   // Once the loop has stopped, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
   // CONFIRMED on the whole panel:  max |1/2 A(K) Q - G|  bounds the next update of every entry of Q, because
   // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
@@ -617,19 +591,26 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // whole-panel confirmation below remains the criterion that counts).
   double tip_tol = predicted ? 0.25 * tol : tol;
   uint32_t enqueued = 0;                                        // iterations enqueued so far (k of the next one)
+  uint32_t prev_partials = 0;                                   // what the previous step left in its half of d_partial
   auto enqueue_chunk = [&](uint32_t slot) -> int {
     for (uint32_t i = 0; i < kChunk; ++i, ++enqueued) {
       const uint32_t k = enqueued;
       sri::QuatEpilogue epi{d_qe, h->d_leg};
       epi.tips_prev = h->d_tips + ((k + 1) & 1) * cols;
-      epi.partial = h->d_partial;
+      epi.partial = h->d_partial + (k & 1) * h->cap_partial;
       epi.stop = h->d_state;
+      // the loop control rides in the step: step k first folds what step k-1 left, decides, and only then computes
+      epi.fold = h->d_partial + ((k + 1) & 1) * h->cap_partial;
+      epi.fold_n = prev_partials;
+      epi.iteration = k;
+      epi.fold_tol = tip_tol;
+      epi.fold_max_iter = max_iter;
+      epi.state = h->d_state;
       uint32_t partials = h->cap_partial;
       int r = sri::integrate_quat_step(h->integ, bufs[k & 1], ldw, h->d_xb4, epi, bufs[(k + 1) & 1], ldw, cols,
                                        h->d_tips + (k & 1) * cols, stream, &partials);
       if (r != SRI_OK) return r;
-      ROD_HIP(sri::launch_kernel(sri::picard_control_kernel, dim3(1), dim3(256), 0, stream, h->d_partial, partials, tip_tol,
-                         static_cast<unsigned long long>(max_iter), h->d_state));
+      prev_partials = partials;
     }
     ROD_HIP(hipMemcpyAsync(h_state + 4 * slot, h->d_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     ROD_HIP(hipEventRecord(done[slot], stream));

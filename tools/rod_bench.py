@@ -91,6 +91,13 @@ def main():
         "fused_step_hbm_GBps": el(8, ms_step),
         "model_ms": iters * ms_step + ms_strain + 2 * ms_qrhs + ms_prhs + ms_apply4 * 1.75,
     }
+    # The pipeline as ONE number against the fp64 MFMA peak: the O(N^2) work it has to do — `iters` fused steps, the final
+    # quaternion apply (4 columns) and the position apply (3 columns), 2 m^2 flop per column each — over the wall time
+    # of the whole solve (coarse start, prolongation, confirmation and elementwise kernels included in the time, not in the flops).
+    pipeline_flops = 2.0 * m * m * rods * (4.0 * iters + 4.0 + 3.0)
+    res["pipeline_algorithmic_GFLOP"] = pipeline_flops / 1e9
+    res["pipeline_TFLOPs"] = pipeline_flops / best / 1e12
+    res["pipeline_frac_of_fp64_mfma_peak_78.6"] = pipeline_flops / best / 1e12 / 78.6
     # CPU baseline: the oracle's restatement of main.cpp (dense per-rod solve), single thread, bounded sample
     try:
         if args.no_cpu:
