@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRI_ABI_VERSION 2
+#define SRI_ABI_VERSION 3
 
 typedef enum sri_status {
     SRI_OK = 0,

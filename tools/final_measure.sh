@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-end measurements on the GPU box (one gpurun call): bench lines, rocprofv3 summaries, step / rod / parity reports.
+#   tools/final_measure.sh <tag>        -> gpurun_out/<tag>_* and profiles/<tag>_* (copy what you want judged into profiles/)
+tag=${1:-r03}
+mkdir -p gpurun_out
+python bench.py > gpurun_out/${tag}_bench_n256.json 2> gpurun_out/${tag}_bench_n256.err; echo "bench cfg3 rc=$?"
+python bench.py --config 2 --steps 20000 --warmup 1000 > gpurun_out/${tag}_bench_cfg2.json 2>/dev/null; echo "bench cfg2 rc=$?"
+python bench.py --config 5 --steps 1000 > gpurun_out/${tag}_bench_cfg5.json 2>/dev/null; echo "bench cfg5 rc=$?"
+python bench.py --operator dnn_inv > gpurun_out/${tag}_bench_dnn_inv_255.json 2>/dev/null; echo "bench dnn_inv rc=$?"
+PROFILE_STEPS=200 tools/profile_bench.sh ${tag}_cfg3 > gpurun_out/prof_${tag}_cfg3.log 2>&1; echo "profile cfg3 rc=$?"
+PROFILE_STEPS=5000 tools/profile_bench.sh ${tag}_cfg2 --config 2 > gpurun_out/prof_${tag}_cfg2.log 2>&1; echo "profile cfg2 rc=$?"
+PROFILE_STEPS=200 tools/profile_bench.sh ${tag}_dnn_inv_255 --operator dnn_inv > gpurun_out/prof_${tag}_255.log 2>&1; echo "profile 255 rc=$?"
+python tools/step_bench.py > gpurun_out/${tag}_step_bench.json 2>/dev/null; echo "step_bench rc=$?"
+python tools/parity_report.py > gpurun_out/${tag}_parity_report.json 2>/dev/null; echo "parity_report rc=$?"
+tools/profile_rod.sh ${tag} > gpurun_out/prof_rod_${tag}.log 2>&1; echo "profile_rod rc=$?"
+cp profiles/${tag}_* profiles/hbm_traffic_* gpurun_out/ 2>/dev/null
+grep -h -o '"frac": [0-9.]*' gpurun_out/${tag}_bench_*.json
