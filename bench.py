@@ -188,7 +188,36 @@ def cpu_baseline(n: int, budget_s: float, data: str, max_rods: int = 65536):
         "all_cores_value": rods_mt / bm, "all_cores_median_value": rods_mt / mm, "all_cores": threads,
         "all_cores_sample": f"{rods_mt} rods, OpenMP over column blocks on {threads} threads (affinity mask / cgroup quota; "
                             f"the host reports {os.cpu_count()} logical CPUs), min of {reps}",
+        "eigen": eigen_baseline(n, rods),
     }
+
+
+def eigen_baseline(n: int, rods: int):
+    """SURVEY §8(d) CPU plan item 3: if a REAL <Eigen/Dense> is installed on this box (never this repo's compat/
+    stand-ins), time the reference's own library doing the reference's own product — Eigen's `A * X`, one thread — as the
+    "reference-library" figure.  Returns {"available": False, ...} where there is none (this pool's image)."""
+    import shutil
+    import tempfile
+
+    cands = [os.environ.get("EIGEN3_INCLUDE_DIR"), "/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/homebrew/include/eigen3",
+             "/usr/include", "/usr/local/include"]
+    inc = next((c for c in cands if c and os.path.exists(os.path.join(c, "Eigen", "Dense"))
+                and os.path.realpath(c) != os.path.realpath(os.path.join(ROOT, "compat"))), None)
+    gxx = shutil.which("g++")
+    if inc is None or gxx is None:
+        return {"available": False, "searched": [c for c in cands if c]}
+    try:
+        outdir = os.path.join(ROOT, "oracle", "_ref")
+        os.makedirs(outdir, exist_ok=True)
+        exe = os.path.join(outdir, "eigen_baseline")
+        subprocess.check_call([gxx, "-O3", "-march=native", "-std=c++17", "-I" + inc, os.path.join(ROOT, "oracle", "eigen_baseline.cpp"), "-o", exe],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        r = subprocess.run([exe, str(n), str(min(rods, 2048)), "5"], capture_output=True, text=True, timeout=300)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"available": True, "value": rec["rod_states_per_s"], "unit": "rod-states/s", "cores": 1, "kind": "reference-library",
+                "sample": f"Eigen {rec['eigen_version']} A*X, one thread, {rec['rods']} rods x 4 cols at N={n} (include dir {inc})"}
+    except Exception as e:                                  # noqa: BLE001 — a baseline that cannot be built is reported, not fatal
+        return {"available": False, "error": str(e)[:200]}
 
 
 def host_panel(n: int, rods: int, data: str, seed: int) -> np.ndarray:

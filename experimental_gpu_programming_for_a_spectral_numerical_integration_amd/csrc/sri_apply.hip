@@ -1411,7 +1411,7 @@ struct sri_apply_handle {
   double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
-  const char* last_kernel = "none";
+  std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events and device slots, built on first use
 };
 
@@ -1707,7 +1707,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   if (rc != SRI_OK) return rc;
 
   if (h->d_apack_small != nullptr && !rank1 && quat == nullptr && many == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
-    h->last_kernel = "sri_apply_mfma_f64<64x64,dma,one-tile-per-workgroup>";
+    h->last_kernel.store("sri_apply_mfma_f64<64x64,dma,one-tile-per-workgroup>", std::memory_order_relaxed);
     return small_launch(h->d_apack_small, dX, ldx, dY, ldy, M, d_tips, h->device, h->num_cus, h->max_workgroups, stream);
   }
 
@@ -1757,7 +1757,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.tail_k = h->rows % 16;
   // (many panels: their bases are only known on the device — plain stores)
   args.nt_stores = (many == nullptr && ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
-  h->last_kernel = kernel_name(h->geo, dma, quat != nullptr);
+  h->last_kernel.store(kernel_name(h->geo, dma, quat != nullptr), std::memory_order_relaxed);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);
   return dispatch<GeoTall>(h, args, dma, rank1, stream, partials);
@@ -2118,7 +2118,7 @@ int sri_apply_destroy(sri_apply_t* h) {
   return SRI_OK;
 }
 
-const char* sri_apply_last_kernel(const sri_apply_t* h) { return h ? h->last_kernel : "none"; }
+const char* sri_apply_last_kernel(const sri_apply_t* h) { return h ? h->last_kernel.load(std::memory_order_relaxed) : "none"; }
 
 int sri_apply_summation_order(const sri_apply_t* h, int* ascending) {
   if (h == nullptr || ascending == nullptr) return SRI_EINVAL;

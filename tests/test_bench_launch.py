@@ -96,3 +96,21 @@ def test_host_and_device_panels_are_the_same_field():
         assert np.allclose(x[r, 3], np.cos(np.sqrt((x[r, :3] ** 2).sum(axis=0))), atol=1e-14)
     H = bench.host_panel(32, 5, "rod", 7)
     assert H.shape == (32, 20) and H.flags.f_contiguous
+
+
+def test_eigen_reference_library_baseline_is_probed_not_faked():
+    """SURVEY 8(d) CPU plan item 3: bench.py times Eigen's own A*X where a REAL Eigen is installed, and says so where it
+    is not (this image) — it must never build against this repo's compat/ stand-ins."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    r = bench.eigen_baseline(64, 64)
+    assert r["available"] in (True, False)
+    if not r["available"]:
+        assert "searched" in r or "error" in r
+    os.environ["EIGEN3_INCLUDE_DIR"] = os.path.join(ROOT, "compat")        # pointing it at the stand-ins must not count
+    try:
+        r2 = bench.eigen_baseline(64, 64)
+        assert r2["available"] == r["available"]
+    finally:
+        del os.environ["EIGEN3_INCLUDE_DIR"]

@@ -239,3 +239,57 @@ def test_mfma_arithmetic_models(oracle):
     err = {m: np.linalg.norm(oracle.model_apply(A, X, m) - Yx) / np.linalg.norm(Yx) for m in (0, 4, 5)}
     assert err[oracle.MODEL_ASCENDING_FMA] < err[oracle.MODEL_ASCENDING_MULADD] < err[oracle.MODEL_KERNEL]
     assert err[oracle.MODEL_ASCENDING_MULADD] <= 1.2e-12 and err[oracle.MODEL_ASCENDING_FMA] <= 0.8e-12
+
+
+# ---- the parity gate itself (oracle.parity_gate: what the GPU tests, smoke() and bench.py all call) --------------------
+def test_parity_gate_accepts_the_kernels_arithmetic_and_rejects_anything_else(oracle):
+    from conftest import rod_strain_panel, uniform_panel
+
+    n = 64
+    A = oracle.dn(n)
+    X = uniform_panel(n, 96)
+    Ymodel = oracle.model_apply(A, X, oracle.MODEL_KERNEL)           # what the GPU must return for a paired-order handle
+    g = oracle.parity_gate(A, X, Ymodel, n, ascending=False)
+    assert g["ok"] and g["gate"] == oracle.GATE_FRO and g["bit_exact_vs_fma_model"] and g["failures"] == []
+    assert g["fro_vs_oracle"] <= 1e-12 and g["backward"] <= g["backward_bound"]
+    # the same numbers judged against the OTHER k order: close to the oracle, but not the kernel's bits
+    g = oracle.parity_gate(A, X, Ymodel, n, ascending=True)
+    assert not g["ok"] and not g["bit_exact_vs_fma_model"] and "FMA-chain model" in g["failures"][0]
+    # one element off by one ulp: every norm still passes, bit-equality does not
+    Y1 = Ymodel.copy()
+    Y1[3, 5] = np.nextafter(Y1[3, 5], np.inf)
+    g = oracle.parity_gate(A, X, Y1, n, ascending=False)
+    assert not g["ok"] and g["fro_vs_oracle"] <= 1e-12
+    # a wrong operator entry (the `make broken` build of the library: 2^-20 relative): caught by the norms as well
+    A2 = A.copy()
+    A2[0, 0] *= 1 + 2.0 ** -20
+    g = oracle.parity_gate(A, X, oracle.model_apply(A2, X, oracle.MODEL_KERNEL), n, ascending=False)
+    assert not g["ok"] and any("fro" in f for f in g["failures"])
+    # NaN in the result
+    Y2 = Ymodel.copy()
+    Y2[0, 0] = np.nan
+    assert not oracle.parity_gate(A, X, Y2, n, ascending=False)["ok"]
+
+
+def test_parity_gate_cancellation_tier_is_only_for_the_declared_regime(oracle):
+    """A product that is 1.5e-12 from the oracle (but closer to binary128 than the oracle is) passes ONLY when the caller
+    declares the cancellation-limited regime; and not even then without the binary128 product."""
+    from conftest import rod_strain_panel
+
+    n = 1024                                                         # the one regime where the oracle itself is ~0.9e-12 from exact
+    A = oracle.dn(n)
+    X = rod_strain_panel(n, 8)
+    Yx = oracle.apply_exact(A, X)                                    # binary128 product, rounded once
+    Yref = oracle.apply(A, X, threads=0)
+    E = Yref - Yx
+    assert 5e-13 < np.linalg.norm(E) / np.linalg.norm(Yx) < 1.5e-12
+    Y = Yx - 0.3 * E                                                 # closer to exact than the oracle, on the far side of it
+    fro = np.linalg.norm(Y - Yref) / np.linalg.norm(Yref)
+    assert 1e-12 < fro <= 2e-12
+    # (bit-equality with the model fails for this synthetic Y in every call; what is tested is the Frobenius tier)
+    plain = oracle.parity_gate(A, X, Y, n, ascending=False)
+    assert any(f.startswith("fro") for f in plain["failures"]) and plain["gate"] == oracle.GATE_FRO
+    declared = oracle.parity_gate(A, X, Y, n, ascending=False, cancellation_limited=True)
+    assert declared["gate"] == oracle.GATE_CANCELLATION and not any(f.startswith("fro") for f in declared["failures"])
+    no_exact = oracle.parity_gate(A, X, Y, n, ascending=False, cancellation_limited=True, exact=False)
+    assert any("binary128 product skipped" in f for f in no_exact["failures"])
