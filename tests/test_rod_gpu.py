@@ -262,7 +262,8 @@ def test_strongly_curved_rods(sri, oracle, n, scale):
     Qo, Ro = _oracle_rods(oracle, n, qe)
     relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
     relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
-    assert relq <= 2e-12 and relr <= 2e-12, (relq, relr, rod.iterations, rod.last_update)
+    # north_star's bar, no special tier: measured 1.4e-15 ... 1.6e-14 on the three cases (round 3)
+    assert relq <= 1e-12 and relr <= 1e-12, (relq, relr, rod.iterations, rod.last_update)
 
 
 def test_fused_step_randomised_sweep(sri):
