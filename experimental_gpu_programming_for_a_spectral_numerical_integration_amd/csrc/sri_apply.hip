@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // DMA filled) — after its own vmcnt wait and BEFORE the stage's barrier: one lane per column, one 8-byte ds_write per
   // slot (one slot for the N - 1 = 255, 1023, ... rows of the integration operators), no extra barrier.
   auto tail_fix_fast = [&](uint32_t slot) __attribute__((always_inline)) {
-    const uint32_t tail_k = SRI_ARGS_HERE.tail_k;
+    const uint32_t tail_k = p.tail_k;                        // (resident: a reload here would put a scalar-load latency in front of the barrier)
     if (lane < 8 * G::X_DMA_PER_WAVE) {
       const int cc = (wid + (lane >> 3) * NW) * 8 + (lane & 7);
       char* const colp = smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES;
