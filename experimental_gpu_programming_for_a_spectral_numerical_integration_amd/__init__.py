@@ -414,7 +414,8 @@ class RodIntegrator:
         _chk(load_library().sri_rod_set_resident(self._h, 1 if enable else 0), "sri_rod_set_resident")
 
     def set_predictor(self, enable: bool):
-        """Large grids (N > 64) start the fixed point from an interpolated 32-node solution; False starts from q_init."""
+        """Start the fixed point from an interpolated coarse solution (the default where there is one): a 32-node solution for
+        N > 64, a 16-node one computed on chip for the one-launch pipeline at 16 < N <= 64.  False starts from q_init."""
         _chk(load_library().sri_rod_set_predictor(self._h, 1 if enable else 0), "sri_rod_set_predictor")
 
     def _check_qe(self, qe):

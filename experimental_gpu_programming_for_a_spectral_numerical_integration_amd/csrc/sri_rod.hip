@@ -411,7 +411,8 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
 
 int sri_rod_set_predictor(sri_rod_t* h, int enable) {
   if (h == nullptr) return SRI_EINVAL;
-  if (enable && h->coarse == nullptr) return SRI_EUNSUPPORTED;
+  // large grids start from a 32-node solution (h->coarse), on-chip grids of more than 16 nodes from a 16-node one
+  if (enable && h->coarse == nullptr && !(h->resident != nullptr && h->m >= 16)) return SRI_EUNSUPPORTED;
   h->use_predictor = enable != 0;
   return SRI_OK;
 }
@@ -697,7 +698,7 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
     if (rcg != SRI_OK) return rcg;
     const double qi_default[4] = {1, 0, 0, 0};
     return sri::resident_integrate(h->resident, d_qe, rods, q_init ? q_init : qi_default, r_init, dQ, ldq, dR, ldr, tol, max_iter,
-                                   iters_out, last_update_out, stream);
+                                   iters_out, last_update_out, stream, h->use_predictor);
   }
   if (h == nullptr || (rods > 0 && dR == nullptr) || ldr < h->m) return SRI_EINVAL;
   // streaming path: the confirmation pass of the quaternion loop has Q in registers and leaves b = R(q) e1 in the

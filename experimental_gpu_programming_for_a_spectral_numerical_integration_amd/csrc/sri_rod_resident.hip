@@ -36,6 +36,12 @@ namespace sri {
 typedef double rd2 __attribute__((ext_vector_type(2)));
 typedef double rd4 __attribute__((ext_vector_type(4)));
 
+// A wave's LDS image is written element by element by every lane and read back as MFMA fragments that OTHER lanes wrote.  The
+// hardware keeps one wave's LDS operations in order, but the compiler reasons per lane: a lane's own writes and its fragment
+// reads are provably disjoint addresses, so without this it may move the reads above the writes (seen with the coarse start at
+// TN > 1: the coarse loop iterated on a stale image).  No instruction is emitted.
+__device__ __forceinline__ void wave_image_fence() { asm volatile("" ::: "memory"); }
+
 #define RES_HIP(call)                                            \
   do {                                                           \
     hipError_t e__ = (call);                                     \
@@ -57,6 +63,11 @@ struct ResidentArgs {
   double q0[4], r0[3];
   double tol;
   uint32_t m, max_iter;
+  // coarse start (grids of more than 16 nodes): the packed integration operator of the 16-node grid (256 doubles, -w folded
+  // in as column k = 15), the interpolation matrix from its 16 nodes to the m unknown fine nodes as TM row tiles of
+  // the same fragment layout (TM * 256 doubles), and P1 at the coarse nodes; null = plain start Q^0 = q0
+  const double* cpack;
+  const double* p1c;
 };
 
 // TM row tiles (m <= 16*TM - 1), TN column tiles of 16 columns = 4 rods per wave task, NW waves per workgroup.
@@ -65,7 +76,9 @@ struct ResGeo {
   static constexpr int A_BYTES = TM * TM * 2048;
   static constexpr int CHUNK_BYTES = TN * 16 * 128;            // one k chunk of a wave's image
   static constexpr int IMG_BYTES = TM * CHUNK_BYTES;
-  static constexpr int LDS_BYTES = A_BYTES + NW * IMG_BYTES + NW * 16;
+  static constexpr int C_BYTES = TM >= 2 ? (1 + TM) * 2048 : 0;   // coarse operator + interpolation tiles (coarse start)
+  static constexpr int C_OFFSET = A_BYTES + NW * IMG_BYTES + NW * 16;
+  static constexpr int LDS_BYTES = C_OFFSET + C_BYTES;
   static constexpr int THREADS = 64 * NW;
   static constexpr int RODS_PER_TASK = 4 * TN;
   static_assert(LDS_BYTES <= 160 * 1024, "operator + wave images exceed a CU");
@@ -85,6 +98,20 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
   // operator -> LDS, once per workgroup (the packed layout is the read layout: a linear copy)
   for (int i = tid; i < G::A_BYTES / 16; i += G::THREADS)
     reinterpret_cast<rd2*>(smem)[i] = reinterpret_cast<const rd2*>(p.apack)[i];
+  // Coarse start (nested iteration, as the streaming path's predictor — sri_rod.hip — but on chip): plain Picard from
+  // Q = q0 needs ~22 sweeps because its error decays like (|K|/2)^k / k!; the strain fields are quadratic polynomials
+  // (utilities.h:49-67), the solution is analytic, and a 16-node grid resolves it to ~1e-9.  So the wave first runs
+  // the SAME fixed point on the 16-node grid in chunk 0 of its image (one 16 x 16 operator tile: TM^2 times cheaper per
+  // sweep), interpolates Q to the fine nodes with one more MFMA product (the interpolation matrix packed like an operator
+  // column block) and starts the fine loop from G^0 = 1/2 A(K) P [Q_c; q0].  The fine loop, its stopping criterion and
+  // everything after it are unchanged: the result is still the fixed point of the FINE system.
+  const bool coarse = TM >= 2 && p.cpack != nullptr;          // uniform over the grid
+  char* const cop = smem + G::C_OFFSET;                       // coarse operator (2 KiB), then TM interpolation tiles
+  if constexpr (TM >= 2) {
+    if (coarse)
+      for (int i = tid; i < G::C_BYTES / 16; i += G::THREADS)
+        reinterpret_cast<rd2*>(cop)[i] = reinterpret_cast<const rd2*>(p.cpack)[i];
+  }
   __syncthreads();
 
   char* img = smem + G::A_BYTES + wid * G::IMG_BYTES;
@@ -106,6 +133,13 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
     p2[tm] = ((2 * 1 + 1) * p1[tm] * p1[tm] - 1 * 1.0) / (1 + 1);            // as strain_kernel (sri_rod.hip)
   }
 
+  double p1c = 0.0, p2c = 0.0;                                 // P1, P2 at coarse node c (lane & 15)
+  if constexpr (TM >= 2) {
+    if (coarse) {
+      p1c = p.p1c[c];
+      p2c = ((2 * 1 + 1) * p1c * p1c - 1 * 1.0) / (1 + 1);
+    }
+  }
   const size_t ntasks = (p.rods + G::RODS_PER_TASK - 1) / G::RODS_PER_TASK;
   uint32_t worst_it = 0;
   double worst_upd = 0.0;
@@ -113,6 +147,7 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
   // Y = A * image for this wave's columns: acc[tm][tn][r] = Y[16 tm + c][16 tn + 4 g + r]
   rd4 acc[TM][TN];
   auto product = [&]() __attribute__((always_inline)) {
+    wave_image_fence();
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -148,6 +183,7 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
     const size_t rod0 = task * G::RODS_PER_TASK + g;              // this lane's rod in column tile tn is rod0 + 4 tn
     // K/2 at this lane's (row, rod) pairs — invariant over the iteration
     double hk[TM][TN][3];
+    double hkc[TN][3];                                           // ... and at coarse node c (coarse start only)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       size_t rod = rod0 + 4 * tn;
@@ -165,15 +201,106 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
           s = s + p2[tm] * q9[a * 3 + 2];
           hk[tm][tn][a] = 0.5 * s;
         }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double s = q9[a * 3 + 0];
+        s = s + p1c * q9[a * 3 + 1];
+        s = s + p2c * q9[a * 3 + 2];
+        hkc[tn][a] = 0.5 * s;
+      }
     }
-    // image <- G^0 = 1/2 A(K) q0 at the unknown nodes; slot k = m <- q0 (the base value of every column); rest 0
+    bool predicted = false;
+    if constexpr (TM >= 2) {
+      if (coarse) {
+        // ---- the same fixed point on the 16-node grid, in chunk 0 of the image: rows 0..14 = G_c, row 15 = q0 ---------
+        rd4 accc[TN];
+        auto product_c = [&]() __attribute__((always_inline)) {
+          wave_image_fence();
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) accc[tn] = rd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const rd2 a = *reinterpret_cast<const rd2*>(cop + j * 1024 + lane * 16);
+            rd2 b[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + frag_off(tn, j));
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn) accc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[e], accc[tn], 0, 0, 0);
+          }
+        };
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          double gq[4];
+          quat_rhs_half(hkc[tn][0], hkc[tn][1], hkc[tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r)) = c < 15 ? gq[r] : p.q0[r];
+        }
+        const uint32_t coarse_budget = p.max_iter < 100u ? p.max_iter : 100u;
+        for (uint32_t itc = 0; itc < coarse_budget; ++itc) {
+          product_c();
+          double local = 0.0;
+          if (c < 15) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              double gq[4];
+              quat_rhs_half(hkc[tn][0], hkc[tn][1], hkc[tn][2], accc[tn][0], accc[tn][1], accc[tn][2], accc[tn][3], gq);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                double* slot = reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r));
+                local = __builtin_fmax(local, fabs(gq[r] - *slot));
+                *slot = gq[r];
+              }
+            }
+          }
+          if (wave_max(local) <= 0.25 * p.tol) break;           // wave-uniform
+        }
+        product_c();                                             // Q_c at the 15 unknown coarse nodes; row 15 of the chunk still holds q0
+        if (c < 15) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r)) = accc[tn][r];
+        }
+        // ---- Q at the fine nodes: acc[tm][tn] = P_tile[tm] . [Q_c; q0]  (one k chunk of the "operator" P) ---------------
+        wave_image_fence();
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = rd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          rd2 a[TM], b[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const rd2*>(cop + 2048 + (tm * 2 + j) * 1024 + lane * 16);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + frag_off(tn, j));
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+        }
+        wave_image_fence();                                      // chunk 0 has been read; the fine image is written next
+        predicted = true;
+      }
+    }
+    // image <- G^0 = 1/2 A(K) Q^0 at the unknown nodes (Q^0 = q0, or the interpolated coarse solution in acc); slot k = m <- q0
+    // (the base value of every column); rest 0
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const uint32_t row = tm * 16 + c;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         double gq[4] = {0.0, 0.0, 0.0, 0.0};
-        if (row < p.m) quat_rhs_half(hk[tm][tn][0], hk[tm][tn][1], hk[tm][tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+        if (row < p.m) {
+          if (predicted) quat_rhs_half(hk[tm][tn][0], hk[tm][tn][1], hk[tm][tn][2], acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3], gq);
+          else quat_rhs_half(hk[tm][tn][0], hk[tm][tn][1], hk[tm][tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double v = row < p.m ? gq[r] : (row == p.m ? p.q0[r] : 0.0);
@@ -296,6 +423,8 @@ struct ResidentRod {
   int num_cus = 0;
   double* d_apack = nullptr;
   double* d_p1 = nullptr;
+  double* d_cpack = nullptr;      // coarse start (grids of more than 16 nodes): 16-node operator + interpolation tiles
+  double* d_p1c = nullptr;
   double* d_stats = nullptr;
   double* h_stats = nullptr;      // pinned
   uint32_t cap_blocks = 0;
@@ -338,6 +467,8 @@ int resident_destroy(ResidentRod* h) {
   if (h == nullptr) return SRI_OK;
   if (h->d_apack) (void)hipFree(h->d_apack);
   if (h->d_p1) (void)hipFree(h->d_p1);
+  if (h->d_cpack) (void)hipFree(h->d_cpack);
+  if (h->d_p1c) (void)hipFree(h->d_p1c);
   if (h->d_stats) (void)hipFree(h->d_stats);
   if (h->h_stats) (void)hipHostFree(h->h_stats);
   delete h;
@@ -385,6 +516,40 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out) {
     return fail(SRI_ENOMEM);
   if (hipMemcpy(h->d_apack, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   if (hipMemcpy(h->d_p1, p1.data(), p1.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+  if (TM >= 2) {
+    // coarse start: the integration operator of the 16-node grid (one 16 x 16 tile, -w_c folded in as column k = 15) and
+    // the interpolation matrix from its 16 nodes (15 unknown + the base node, in that order: both grids descend from the
+    // tip to the base, chebyshev_differentiation.h:26) to the m unknown fine nodes, as TM row tiles of one k chunk
+    constexpr uint32_t nc = 16, mc = 15;
+    std::vector<double> Ac(mc * mc), Dinc(mc), wc(mc, 0.0), xc(nc), Pm(static_cast<size_t>(n) * nc);
+    rc = cheb_integration(nc, Ac.data(), mc, Dinc.data());
+    if (rc == SRI_OK) rc = cheb_interp(nc, n, Pm.data(), n);
+    if (rc != SRI_OK) return fail(rc);
+    for (uint32_t k = 0; k < mc; ++k)
+      for (uint32_t i = 0; i < mc; ++i) wc[i] = wc[i] + Ac[i + static_cast<size_t>(k) * mc] * Dinc[k];
+    cheb_points(nc, 1.0, xc.data());
+    std::vector<double> cpack(static_cast<size_t>(1 + TM) * 256, 0.0), p1c(nc, 0.0);
+    o = 0;
+    for (int j = 0; j < 2; ++j)
+      for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 2; ++e, ++o) {
+          const uint32_t row = l & 15, k = k_of_paired(j, l >> 4, e);
+          if (row < mc && k < mc) cpack[o] = Ac[row + static_cast<size_t>(k) * mc];
+          else if (row < mc && k == mc) cpack[o] = -wc[row];
+        }
+    for (int tm = 0; tm < TM; ++tm)
+      for (int j = 0; j < 2; ++j)
+        for (int l = 0; l < 64; ++l)
+          for (int e = 0; e < 2; ++e, ++o) {
+            const uint32_t row = tm * 16 + (l & 15), k = k_of_paired(j, l >> 4, e);
+            if (row < m) cpack[o] = Pm[row + static_cast<size_t>(k) * n];
+          }
+    for (uint32_t i = 0; i < nc; ++i) p1c[i] = (2 * xc[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+    if (hipMalloc(&h->d_cpack, cpack.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+    if (hipMalloc(&h->d_p1c, p1c.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+    if (hipMemcpy(h->d_cpack, cpack.data(), cpack.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+    if (hipMemcpy(h->d_p1c, p1c.data(), p1c.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+  }
   *out = h;
   return SRI_OK;
 }
@@ -392,7 +557,7 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out) {
 // Quaternions (dR == nullptr) or quaternions + positions of `rods` rods; synchronises the stream once (statistics).
 int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
                        size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
-                       double* last_update_out, void* stream_) {
+                       double* last_update_out, void* stream_, bool coarse_start) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ResidentArgs args;
   args.apack = h->d_apack;
@@ -409,6 +574,8 @@ int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const do
   args.tol = tol;
   args.m = h->m;
   args.max_iter = max_iter;
+  args.cpack = coarse_start ? h->d_cpack : nullptr;            // (null for grids of 16 nodes or fewer: nothing coarser to start from)
+  args.p1c = h->d_p1c;
   uint32_t blocks = 0;
   int rc;
   switch (h->tm) {

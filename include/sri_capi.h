@@ -172,10 +172,12 @@ int sri_rod_destroy(sri_rod_t *h);
  * streaming path (one fused launch per iteration) that larger grids use; SRI_EUNSUPPORTED if enabling is impossible. */
 int sri_rod_set_resident(sri_rod_t *h, int enable);
 
-/* Large grids (N > 64) start the fixed point from a coarse-grid solution: the same rods on a 32-node Chebyshev grid
- * (on-chip pipeline), interpolated to the fine nodes.  The result is still the fixed point of the fine system, tested
- * and confirmed as without it; only the iteration count changes (*iters counts fine-grid iterations).  enable = 0
- * starts from Q = q_init at every node instead; SRI_EUNSUPPORTED if enabling is impossible (N <= 64). */
+/* Grids of more than 16 nodes start the fixed point from a coarse-grid solution: the same rods on a 32-node Chebyshev grid
+ * (N > 64: on-chip pipeline, then interpolated by a kernel) or on a 16-node grid inside the on-chip pipeline itself
+ * (16 < N <= 64), interpolated to the fine nodes.  The result is still the fixed point of the fine system, tested and
+ * confirmed as without it; only the iteration count changes (*iters counts fine-grid iterations).  enable = 0 starts
+ * from Q = q_init at every node instead; SRI_EUNSUPPORTED if enabling is impossible (N <= 16, or no coarser grid
+ * fits: (N-1) % 16 == 0 below 65). */
 int sri_rod_set_predictor(sri_rod_t *h, int enable);
 
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):

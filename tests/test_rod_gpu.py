@@ -160,7 +160,13 @@ def test_resident_and_streaming_paths_agree(sri):
     Qb, Rb = rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
     torch.cuda.synchronize()
     assert (Qa - Qb).abs().max().item() <= 1e-13 and (Ra - Rb).abs().max().item() <= 1e-13
-    assert abs(it_res - rod.iterations) <= 3
+    assert it_res < rod.iterations                               # the on-chip pipeline starts from its 16-node solution
+    rod.set_resident(True)
+    rod.set_predictor(False)
+    rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
+    assert abs(rod.iterations - it_res) >= 3 and abs(rod.iterations - 22) <= 6   # plain start: the streaming path's count
+    rod.set_predictor(True)
+    rod.set_resident(False)
     for n in (17, 65, 256):                                      # (N-1) % 16 == 0, or too large
         big = sri.RodIntegrator(n)
         with pytest.raises(sri.SriError) as e:
@@ -224,10 +230,40 @@ def test_large_grid_predictor_matches_oracle_and_plain_start(sri, oracle, n, rod
         assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
     assert (Qp - Qn).abs().max().item() <= 1e-13
     assert it_pred <= 8 < it_plain, (it_pred, it_plain)
-    small = sri.RodIntegrator(32)
+    small = sri.RodIntegrator(16)                                # nothing coarser than the 16-node grid to start from
     with pytest.raises(sri.SriError) as e:
         small.set_predictor(True)
     assert e.value.status == -6
+
+
+@pytest.mark.parametrize("n,rods", [(32, 700), (48, 333), (64, 1500), (20, 64), (63, 40)])
+def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rods):
+    """16 < N <= 64 (round 3): the on-chip pipeline first solves the rods on a 16-node grid inside the same launch and
+    starts the fine fixed point from the interpolated solution.  Same fixed point as the plain start (1e-13), same
+    distance to the oracle's dense solve, a fraction of the sweeps."""
+    import torch
+
+    qe = _qe_batch(rods, seed=1000 + n)
+    dqe = torch.from_numpy(qe).cuda()
+    q_init = np.array([0.8, 0.0, 0.6, 0.0])
+    r_init = np.array([0.5, -1.0, 2.0])
+    rod = sri.RodIntegrator(n)
+    Qp, Rp = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_pred = rod.iterations
+    assert rod.last_update <= 1e-14
+    rod.set_predictor(False)
+    Qn, Rn = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_plain = rod.iterations
+    rod.set_predictor(True)
+    torch.cuda.synchronize()
+    sample = slice(0, min(rods, 24))
+    Qo, Ro = _oracle_rods(oracle, n, qe[sample], q_init, r_init)
+    for Q, R in ((Qp, Rp), (Qn, Rn)):
+        relq = np.linalg.norm(Q[sample].cpu().numpy() - Qo) / np.linalg.norm(Qo)
+        relr = np.linalg.norm(R[sample].cpu().numpy() - Ro) / np.linalg.norm(Ro)
+        assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
+    assert (Qp - Qn).abs().max().item() <= 1e-13 and (Rp - Rn).abs().max().item() <= 1e-13
+    assert it_pred < it_plain and it_pred <= 16, (it_pred, it_plain)
 
 
 @pytest.mark.parametrize("n,rods", [(17, 9), (33, 21), (65, 6), (97, 4)])

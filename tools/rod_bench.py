@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--oracle-rods", type=int, default=4, help="rods compared with the CPU oracle's dense solve (max abs error of Q and r)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline (profiling runs)")
     ap.add_argument("--streaming", action="store_true", help="force the streaming path (one fused launch per iteration) on small grids")
+    ap.add_argument("--no-coarse-start", action="store_true", help="start the fixed point from q0 instead of the 16-node solution")
     args = ap.parse_args()
     n, rods, m = args.n, args.rods, args.n - 1
     dev = torch.device("cuda", 0)
@@ -49,6 +50,11 @@ def main():
     resident = m <= 63 and m % 16 != 0 and not args.streaming
     if m <= 63 and m % 16 != 0:
         rod.set_resident(resident)
+    coarse_start = not args.no_coarse_start
+    try:
+        rod.set_predictor(coarse_start)
+    except RuntimeError:                                          # this grid has no coarse start (N <= 16, or N - 1 in {32, 48})
+        coarse_start = False
     g = torch.Generator(device=dev).manual_seed(0x5EED)
     qe = (torch.rand((rods, 9), dtype=torch.float64, device=dev, generator=g) * 2 - 1) * args.scale
     # clock ramp
@@ -78,7 +84,7 @@ def main():
     res = {
         "metric": "rods/s (quaternion + position integration, fp64)", "value": rods / best, "unit": "rods/s",
         "n": n, "rods": rods, "path": "resident (one launch, state in LDS)" if resident else "streaming (one fused launch per iteration)",
-        "qe_scale": args.scale, "tol": args.tol, "ms_total": best * 1e3, "picard_iterations": iters,
+        "coarse_start": coarse_start, "qe_scale": args.scale, "tol": args.tol, "ms_total": best * 1e3, "picard_iterations": iters,
         "last_update": rod.last_update,
         "unit_quaternion_defect_max": float((Q.pow(2).sum(dim=1).sqrt() - 1).abs().max()),
         "breakdown_ms": {"strain_field": ms_strain, "quaternion_rhs": ms_qrhs, "position_rhs": ms_prhs,
