@@ -1774,6 +1774,12 @@ uint32_t max_partials(const sri_apply_t* h) { return h ? static_cast<uint32_t>(h
 
 uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 0; }
 
+// w = Dn_NN^-1 Dn_IN of an integration handle exactly as the kernel applies it (rows doubles, host).
+int ivp_weights(const sri_apply_t* h, double* w_host) {
+  if (h == nullptr || w_host == nullptr || h->which != SRI_OP_DNN_INV || h->d_w == nullptr) return SRI_EINVAL;
+  return hipMemcpy(w_host, h->d_w, sizeof(double) * h->rows, hipMemcpyDeviceToHost) == hipSuccess ? SRI_OK : SRI_EHIP;
+}
+
 }  // namespace sri
 
 // ------------------------------------------------------------------------------------------

@@ -52,6 +52,7 @@ int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const doub
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials = nullptr);
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
+int ivp_weights(const sri_apply_t* h, double* w_host);   // w = Dn_NN^-1 Dn_IN as the handle applies it (rows doubles); `device` current
 
 // ---- the latency kernel for 64-row operators and small batches: one tile per workgroup (sri_apply_small.hip) ---------
 constexpr uint32_t kSmallRows = 64;
@@ -65,7 +66,10 @@ int small_launch(const double* d_apack, const double* dX, size_t ldx, double* dY
 // ---- on-chip rod pipeline for small grids (sri_rod_resident.hip, used by sri_rod.hip) -----------------------------
 struct ResidentRod;
 bool resident_supported(uint32_t m);                 // m = N - 1 <= 63 and m % 16 != 0
-int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out);   // `device` must be current
+// `device` must be current.  A_fine / w_fine / n_fine: this handle is the coarse start of an n_fine-node grid whose integration
+// operator is A_fine ((n_fine-1)^2, column-major) with initial-value weights w_fine — see coarse_view_of_fine_operator.
+int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, const double* A_fine = nullptr,
+                    const double* w_fine = nullptr, uint32_t n_fine = 0);
 int resident_destroy(ResidentRod* h);
 int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
                        size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,

@@ -236,6 +236,26 @@ def test_large_grid_predictor_matches_oracle_and_plain_start(sri, oracle, n, rod
     assert e.value.status == -6
 
 
+@pytest.mark.parametrize("n,rods", [(128, 4096), (256, 4096), (512, 1024)])
+def test_predicted_start_is_one_sweep_from_the_fine_fixed_point(sri, oracle, n, rods):
+    """The 32-node solve that starts a large grid uses the FINE integration operator as its own nodes see it (round 3:
+    `coarse_view_of_fine_operator`), so the start does not carry the coarse grid's own ~1e-14 operator error — a smooth
+    error that restarted Picard iteration removed at L/(k+1) per sweep (5-6 sweeps at tol = 1e-14).  What is left is
+    rounding noise, damped by the first sweep.  Oracle distance unchanged."""
+    import torch
+
+    qe = _qe_batch(rods, seed=77 + n)
+    dqe = torch.from_numpy(qe).cuda()
+    rod = sri.RodIntegrator(n)
+    Q, R = rod.integrate(dqe, tol=1e-14)
+    assert rod.iterations <= 3 and rod.last_update <= 1e-14, (rod.iterations, rod.last_update)
+    torch.cuda.synchronize()
+    Qo, Ro = _oracle_rods(oracle, n, qe[:3])
+    relq = np.linalg.norm(Q[:3].cpu().numpy() - Qo) / np.linalg.norm(Qo)
+    relr = np.linalg.norm(R[:3].cpu().numpy() - Ro) / np.linalg.norm(Ro)
+    assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
+
+
 @pytest.mark.parametrize("n,rods", [(32, 700), (48, 333), (64, 1500), (20, 64), (63, 40)])
 def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rods):
     """16 < N <= 64 (round 3): the on-chip pipeline first solves the rods on a 16-node grid inside the same launch and
