@@ -108,6 +108,8 @@ def main():
     try:
         if args.no_cpu:
             raise RuntimeError("skipped (--no-cpu)")
+        if n > 1024:                                              # one dense 4(N-1) inverse per rod: minutes per rod beyond this
+            raise RuntimeError("skipped (the oracle's dense per-rod solve is O(N^3): N > 1024 takes minutes per rod)")
         import oracle
         qh = qe[:64].cpu().numpy()
         t0 = time.perf_counter(); done = 0
