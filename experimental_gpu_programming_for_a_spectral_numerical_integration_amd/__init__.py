@@ -415,7 +415,8 @@ class RodIntegrator:
 
     def set_predictor(self, enable: bool):
         """Start the fixed point from an interpolated coarse solution (the default where there is one): a 32-node solution for
-        N > 64, a 16-node one computed on chip for the one-launch pipeline at 16 < N <= 64.  False starts from q_init."""
+        N > 64; inside the one-launch pipeline a 32-node one for 32 < N <= 64 and a 16-node one for 16 < N <= 32.  False starts
+        from q_init."""
         _chk(load_library().sri_rod_set_predictor(self._h, 1 if enable else 0), "sri_rod_set_predictor")
 
     def _check_qe(self, qe):

@@ -63,9 +63,9 @@ struct ResidentArgs {
   double q0[4], r0[3];
   double tol;
   uint32_t m, max_iter;
-  // coarse start (grids of more than 16 nodes): the packed integration operator of the 16-node grid (256 doubles, -w folded
-  // in as column k = 15), the interpolation matrix from its 16 nodes to the m unknown fine nodes as TM row tiles of
-  // the same fragment layout (TM * 256 doubles), and P1 at the coarse nodes; null = plain start Q^0 = q0
+  // coarse start (grids of more than 16 nodes): the packed integration operator of the coarse grid (16 TMC nodes: TMC^2 tiles
+  // of 256 doubles, -w folded in as column k = 16 TMC - 1), the interpolation matrix from its nodes to the m unknown fine
+  // nodes as TM x TMC tiles of the same fragment layout, and P1 at the coarse nodes; null = plain start Q^0 = q0
   const double* cpack;
   const double* p1c;
 };
@@ -76,7 +76,10 @@ struct ResGeo {
   static constexpr int A_BYTES = TM * TM * 2048;
   static constexpr int CHUNK_BYTES = TN * 16 * 128;            // one k chunk of a wave's image
   static constexpr int IMG_BYTES = TM * CHUNK_BYTES;
-  static constexpr int C_BYTES = TM >= 2 ? (1 + TM) * 2048 : 0;   // coarse operator + interpolation tiles (coarse start)
+  // coarse start: a 16-node grid under fine grids of up to 32 nodes, a 32-node grid (TMC = 2) under larger ones
+  static constexpr int TMC = TM >= 3 ? 2 : 1;
+  static constexpr int COP_BYTES = TMC * TMC * 2048;           // coarse operator tiles, [kc][tmc][j] like the fine one
+  static constexpr int C_BYTES = TM >= 2 ? COP_BYTES + TM * TMC * 2048 : 0;   // ... + interpolation tiles [tm][kc][j]
   static constexpr int C_OFFSET = A_BYTES + NW * IMG_BYTES + NW * 16;
   static constexpr int LDS_BYTES = C_OFFSET + C_BYTES;
   static constexpr int THREADS = 64 * NW;
@@ -100,10 +103,11 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
     reinterpret_cast<rd2*>(smem)[i] = reinterpret_cast<const rd2*>(p.apack)[i];
   // Coarse start (nested iteration, as the streaming path's predictor — sri_rod.hip — but on chip): plain Picard from
   // Q = q0 needs ~22 sweeps because its error decays like (|K|/2)^k / k!; the strain fields are quadratic polynomials
-  // (utilities.h:49-67), the solution is analytic, and a 16-node grid resolves it to ~1e-9.  So the wave first runs
-  // the SAME fixed point on the 16-node grid in chunk 0 of its image (one 16 x 16 operator tile: TM^2 times cheaper per
-  // sweep), interpolates Q to the fine nodes with one more MFMA product (the interpolation matrix packed like an operator
-  // column block) and starts the fine loop from G^0 = 1/2 A(K) P [Q_c; q0].  The fine loop, its stopping criterion and
+  // (utilities.h:49-67), the solution is analytic, and a 16-node grid resolves it to ~1e-9, a 32-node grid to rounding.  So
+  // the wave first runs the SAME fixed point on a coarse grid in the first chunks of its image — 16 nodes (one operator
+  // tile) under fine grids of up to 32 nodes, 32 nodes (2 x 2 tiles: a quarter of a 64-node sweep, and the fine loop then
+  // starts at rounding level) under larger ones — interpolates Q to the fine nodes with one more MFMA product (the
+  // interpolation matrix packed like an operator column block) and starts the fine loop from G^0 = 1/2 A(K) P [Q_c; q0].  The fine loop, its stopping criterion and
   // everything after it are unchanged: the result is still the fixed point of the FINE system.
   const bool coarse = TM >= 2 && p.cpack != nullptr;          // uniform over the grid
   char* const cop = smem + G::C_OFFSET;                       // coarse operator (2 KiB), then TM interpolation tiles
@@ -133,11 +137,17 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
     p2[tm] = ((2 * 1 + 1) * p1[tm] * p1[tm] - 1 * 1.0) / (1 + 1);            // as strain_kernel (sri_rod.hip)
   }
 
-  double p1c = 0.0, p2c = 0.0;                                 // P1, P2 at coarse node c (lane & 15)
-  if constexpr (TM >= 2) {
-    if (coarse) {
-      p1c = p.p1c[c];
-      p2c = ((2 * 1 + 1) * p1c * p1c - 1 * 1.0) / (1 + 1);
+  constexpr int TMC = G::TMC;
+  double p1c[TMC], p2c[TMC];                                   // P1, P2 at coarse node 16 tmc + c
+#pragma unroll
+  for (int tmc = 0; tmc < TMC; ++tmc) {
+    p1c[tmc] = 0.0;
+    p2c[tmc] = 0.0;
+    if constexpr (TM >= 2) {
+      if (coarse) {
+        p1c[tmc] = p.p1c[tmc * 16 + c];
+        p2c[tmc] = ((2 * 1 + 1) * p1c[tmc] * p1c[tmc] - 1 * 1.0) / (1 + 1);
+      }
     }
   }
   const size_t ntasks = (p.rods + G::RODS_PER_TASK - 1) / G::RODS_PER_TASK;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
     const size_t rod0 = task * G::RODS_PER_TASK + g;              // this lane's rod in column tile tn is rod0 + 4 tn
     // K/2 at this lane's (row, rod) pairs — invariant over the iteration
     double hk[TM][TN][3];
-    double hkc[TN][3];                                           // ... and at coarse node c (coarse start only)
+    double hkc[TMC][TN][3];                                      // ... and at the coarse nodes (coarse start only)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       size_t rod = rod0 + 4 * tn;
@@ -202,90 +212,118 @@ __global__ __launch_bounds__(64 * NW, TM == 1 ? 4 : 2) void rod_resident_kernel(
           hk[tm][tn][a] = 0.5 * s;
         }
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        double s = q9[a * 3 + 0];
-        s = s + p1c * q9[a * 3 + 1];
-        s = s + p2c * q9[a * 3 + 2];
-        hkc[tn][a] = 0.5 * s;
-      }
+      for (int tmc = 0; tmc < TMC; ++tmc)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          double s = q9[a * 3 + 0];
+          s = s + p1c[tmc] * q9[a * 3 + 1];
+          s = s + p2c[tmc] * q9[a * 3 + 2];
+          hkc[tmc][tn][a] = 0.5 * s;
+        }
     }
     bool predicted = false;
     if constexpr (TM >= 2) {
       if (coarse) {
-        // ---- the same fixed point on the 16-node grid, in chunk 0 of the image: rows 0..14 = G_c, row 15 = q0 ---------
-        rd4 accc[TN];
+        // ---- the same fixed point on the coarse grid (mc = 16 TMC - 1 unknown nodes), in chunks 0..TMC-1 of the image:
+        //      rows 0..mc-1 = G_c, row mc = q0 ------------------------------------------------------------------------
+        constexpr int mc = 16 * TMC - 1;
+        rd4 accc[TMC][TN];
         auto product_c = [&]() __attribute__((always_inline)) {
           wave_image_fence();
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) accc[tn] = rd4{0.0, 0.0, 0.0, 0.0};
+          for (int tmc = 0; tmc < TMC; ++tmc)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const rd2 a = *reinterpret_cast<const rd2*>(cop + j * 1024 + lane * 16);
-            rd2 b[TN];
+            for (int tn = 0; tn < TN; ++tn) accc[tmc][tn] = rd4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + frag_off(tn, j));
+          for (int kc = 0; kc < TMC; ++kc)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int j = 0; j < 2; ++j) {
+              rd2 a[TMC], b[TN];
 #pragma unroll
-              for (int tn = 0; tn < TN; ++tn) accc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[e], accc[tn], 0, 0, 0);
-          }
+              for (int tmc = 0; tmc < TMC; ++tmc)
+                a[tmc] = *reinterpret_cast<const rd2*>(cop + ((kc * TMC + tmc) * 2 + j) * 1024 + lane * 16);
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + kc * G::CHUNK_BYTES + frag_off(tn, j));
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int tmc = 0; tmc < TMC; ++tmc)
+#pragma unroll
+                  for (int tn = 0; tn < TN; ++tn)
+                    accc[tmc][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tmc][e], accc[tmc][tn], 0, 0, 0);
+            }
         };
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          double gq[4];
-          quat_rhs_half(hkc[tn][0], hkc[tn][1], hkc[tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+        for (int tmc = 0; tmc < TMC; ++tmc) {
+          const int row = tmc * 16 + c;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r)) = c < 15 ? gq[r] : p.q0[r];
+          for (int tn = 0; tn < TN; ++tn) {
+            double gq[4];
+            quat_rhs_half(hkc[tmc][tn][0], hkc[tmc][tn][1], hkc[tmc][tn][2], p.q0[0], p.q0[1], p.q0[2], p.q0[3], gq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<double*>(img + tmc * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r)) = row < mc ? gq[r] : p.q0[r];
+          }
         }
         const uint32_t coarse_budget = p.max_iter < 100u ? p.max_iter : 100u;
         for (uint32_t itc = 0; itc < coarse_budget; ++itc) {
           product_c();
           double local = 0.0;
-          if (c < 15) {
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-              double gq[4];
-              quat_rhs_half(hkc[tn][0], hkc[tn][1], hkc[tn][2], accc[tn][0], accc[tn][1], accc[tn][2], accc[tn][3], gq);
+          for (int tmc = 0; tmc < TMC; ++tmc) {
+            if (tmc * 16 + c < mc) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                double* slot = reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r));
-                local = __builtin_fmax(local, fabs(gq[r] - *slot));
-                *slot = gq[r];
+              for (int tn = 0; tn < TN; ++tn) {
+                double gq[4];
+                quat_rhs_half(hkc[tmc][tn][0], hkc[tmc][tn][1], hkc[tmc][tn][2], accc[tmc][tn][0], accc[tmc][tn][1], accc[tmc][tn][2],
+                              accc[tmc][tn][3], gq);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  double* slot = reinterpret_cast<double*>(img + tmc * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r));
+                  local = __builtin_fmax(local, fabs(gq[r] - *slot));
+                  *slot = gq[r];
+                }
               }
             }
           }
           if (wave_max(local) <= 0.25 * p.tol) break;           // wave-uniform
         }
-        product_c();                                             // Q_c at the 15 unknown coarse nodes; row 15 of the chunk still holds q0
-        if (c < 15) {
+        product_c();                                             // Q_c at the unknown coarse nodes; row mc of the image still holds q0
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
+        for (int tmc = 0; tmc < TMC; ++tmc) {
+          if (tmc * 16 + c < mc) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<double*>(img + elem_off(tn * 16 + 4 * g + r)) = accc[tn][r];
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<double*>(img + tmc * G::CHUNK_BYTES + elem_off(tn * 16 + 4 * g + r)) = accc[tmc][tn][r];
+          }
         }
-        // ---- Q at the fine nodes: acc[tm][tn] = P_tile[tm] . [Q_c; q0]  (one k chunk of the "operator" P) ---------------
+        // ---- Q at the fine nodes: acc[tm][tn] = P_tile[tm][.] . [Q_c; q0]  (TMC k chunks of the "operator" P) ------------
         wave_image_fence();
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = rd4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          rd2 a[TM], b[TN];
+        for (int kc = 0; kc < TMC; ++kc)
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const rd2*>(cop + 2048 + (tm * 2 + j) * 1024 + lane * 16);
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + frag_off(tn, j));
-#pragma unroll
-          for (int e = 0; e < 2; ++e)
+          for (int j = 0; j < 2; ++j) {
+            rd2 a[TM], b[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
+              a[tm] = *reinterpret_cast<const rd2*>(cop + G::COP_BYTES + ((tm * TMC + kc) * 2 + j) * 1024 + lane * 16);
 #pragma unroll
-              for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
-        }
-        wave_image_fence();                                      // chunk 0 has been read; the fine image is written next
+            for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const rd2*>(img + kc * G::CHUNK_BYTES + frag_off(tn, j));
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                  acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+          }
+        wave_image_fence();                                      // the coarse chunks have been read; the fine image is written next
         predicted = true;
       }
     }
@@ -423,7 +461,7 @@ struct ResidentRod {
   int num_cus = 0;
   double* d_apack = nullptr;
   double* d_p1 = nullptr;
-  double* d_cpack = nullptr;      // coarse start (grids of more than 16 nodes): 16-node operator + interpolation tiles
+  double* d_cpack = nullptr;      // coarse start (grids of more than 16 nodes): coarse operator + interpolation tiles
   double* d_p1c = nullptr;
   double* d_stats = nullptr;
   double* h_stats = nullptr;      // pinned
@@ -584,31 +622,36 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, cons
   if (hipMemcpy(h->d_apack, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   if (hipMemcpy(h->d_p1, p1.data(), p1.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   if (TM >= 2) {
-    // coarse start: the integration operator of the 16-node grid (one 16 x 16 tile, -w_c folded in as column k = 15) and
-    // the interpolation matrix from its 16 nodes (15 unknown + the base node, in that order: both grids descend from the
-    // tip to the base, chebyshev_differentiation.h:26) to the m unknown fine nodes, as TM row tiles of one k chunk
-    constexpr uint32_t nc = 16, mc = 15;
+    // coarse start: the fine operator as a coarse grid sees it (16 nodes under fine grids of up to 32, else 32: TMC tiles a
+    // side, -w_c folded in as column k = mc), and the interpolation matrix from the coarse nodes (mc unknown + the base node,
+    // in that order: both grids descend from the tip to the base, chebyshev_differentiation.h:26) to the m unknown fine
+    // nodes, as TM x TMC tiles
+    const int TMC = TM >= 3 ? 2 : 1;
+    const uint32_t nc = 16u * TMC, mc = nc - 1;
     std::vector<double> Ac, wc, xc(nc), Pm(static_cast<size_t>(n) * nc);
     rc = coarse_view_of_fine_operator(A.data(), w.data(), n, nc, Ac, wc);   // what the fine loop will apply, at the coarse nodes
     if (rc == SRI_OK) rc = cheb_interp(nc, n, Pm.data(), n);
     if (rc != SRI_OK) return fail(rc);
     cheb_points(nc, 1.0, xc.data());
-    std::vector<double> cpack(static_cast<size_t>(1 + TM) * 256, 0.0), p1c(nc, 0.0);
+    std::vector<double> cpack(static_cast<size_t>(TMC * TMC + TM * TMC) * 256, 0.0), p1c(nc, 0.0);
     o = 0;
-    for (int j = 0; j < 2; ++j)
-      for (int l = 0; l < 64; ++l)
-        for (int e = 0; e < 2; ++e, ++o) {
-          const uint32_t row = l & 15, k = k_of_paired(j, l >> 4, e);
-          if (row < mc && k < mc) cpack[o] = Ac[row + static_cast<size_t>(k) * mc];
-          else if (row < mc && k == mc) cpack[o] = -wc[row];
-        }
+    for (int kc = 0; kc < TMC; ++kc)
+      for (int tmc = 0; tmc < TMC; ++tmc)
+        for (int j = 0; j < 2; ++j)
+          for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 2; ++e, ++o) {
+              const uint32_t row = tmc * 16 + (l & 15), k = kc * 16 + k_of_paired(j, l >> 4, e);
+              if (row < mc && k < mc) cpack[o] = Ac[row + static_cast<size_t>(k) * mc];
+              else if (row < mc && k == mc) cpack[o] = -wc[row];
+            }
     for (int tm = 0; tm < TM; ++tm)
-      for (int j = 0; j < 2; ++j)
-        for (int l = 0; l < 64; ++l)
-          for (int e = 0; e < 2; ++e, ++o) {
-            const uint32_t row = tm * 16 + (l & 15), k = k_of_paired(j, l >> 4, e);
-            if (row < m) cpack[o] = Pm[row + static_cast<size_t>(k) * n];
-          }
+      for (int kc = 0; kc < TMC; ++kc)
+        for (int j = 0; j < 2; ++j)
+          for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 2; ++e, ++o) {
+              const uint32_t row = tm * 16 + (l & 15), k = kc * 16 + k_of_paired(j, l >> 4, e);
+              if (row < m) cpack[o] = Pm[row + static_cast<size_t>(k) * n];
+            }
     for (uint32_t i = 0; i < nc; ++i) p1c[i] = (2 * xc[i] - (1.0 + 0.0)) / (1.0 - 0.0);
     if (hipMalloc(&h->d_cpack, cpack.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
     if (hipMalloc(&h->d_p1c, p1c.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);

@@ -173,8 +173,9 @@ int sri_rod_destroy(sri_rod_t *h);
 int sri_rod_set_resident(sri_rod_t *h, int enable);
 
 /* Grids of more than 16 nodes start the fixed point from a coarse-grid solution: the same rods on a 32-node Chebyshev grid
- * (N > 64: on-chip pipeline, then interpolated by a kernel) or on a 16-node grid inside the on-chip pipeline itself
- * (16 < N <= 64), interpolated to the fine nodes.  The result is still the fixed point of the fine system, tested and
+ * (N > 64: on-chip pipeline, then interpolated by a kernel) or on a 32- / 16-node grid inside the on-chip pipeline itself
+ * (32 < N <= 64 / 16 < N <= 32), interpolated to the fine nodes.  The coarse solve uses the FINE grid's operator as the
+ * coarse nodes see it, so the start is rounding noise away from the fine fixed point (one fine sweep at N = 64 ... 512).  The result is still the fixed point of the fine system, tested and
  * confirmed as without it; only the iteration count changes (*iters counts fine-grid iterations).  enable = 0 starts
  * from Q = q_init at every node instead; SRI_EUNSUPPORTED if enabling is impossible (N <= 16, or no coarser grid
  * fits: (N-1) % 16 == 0 below 65). */

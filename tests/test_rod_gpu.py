@@ -258,9 +258,10 @@ def test_predicted_start_is_one_sweep_from_the_fine_fixed_point(sri, oracle, n, 
 
 @pytest.mark.parametrize("n,rods", [(32, 700), (48, 333), (64, 1500), (20, 64), (63, 40)])
 def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rods):
-    """16 < N <= 64 (round 3): the on-chip pipeline first solves the rods on a 16-node grid inside the same launch and
-    starts the fine fixed point from the interpolated solution.  Same fixed point as the plain start (1e-13), same
-    distance to the oracle's dense solve, a fraction of the sweeps."""
+    """16 < N <= 64 (round 3): the on-chip pipeline first solves the rods on a coarse grid inside the same launch — 16 nodes
+    under fine grids of up to 32 nodes, 32 nodes under larger ones — and starts the fine fixed point from the interpolated
+    solution.  Same fixed point as the plain start (1e-13), same distance to the oracle's dense solve, a fraction of the
+    sweeps: a 32-node grid resolves these rods to rounding, so the fine loop only confirms (<= 3 sweeps)."""
     import torch
 
     qe = _qe_batch(rods, seed=1000 + n)
@@ -283,7 +284,7 @@ def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rod
         relr = np.linalg.norm(R[sample].cpu().numpy() - Ro) / np.linalg.norm(Ro)
         assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
     assert (Qp - Qn).abs().max().item() <= 1e-13 and (Rp - Rn).abs().max().item() <= 1e-13
-    assert it_pred < it_plain and it_pred <= 16, (it_pred, it_plain)
+    assert it_pred < it_plain and it_pred <= (16 if n <= 32 else 3), (it_pred, it_plain)
 
 
 @pytest.mark.parametrize("n,rods", [(17, 9), (33, 21), (65, 6), (97, 4)])
