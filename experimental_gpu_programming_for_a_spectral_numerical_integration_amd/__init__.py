@@ -410,7 +410,7 @@ class RodIntegrator:
         return torch.cuda.current_stream(t.device).cuda_stream
 
     def set_resident(self, enable: bool):
-        """Small grids (N <= 64, (N-1) % 16 != 0) use the on-chip one-launch pipeline; False forces the streaming path."""
+        """Small grids (N <= 64) use the on-chip one-launch pipeline; False forces the streaming path."""
         _chk(load_library().sri_rod_set_resident(self._h, 1 if enable else 0), "sri_rod_set_resident")
 
     def set_predictor(self, enable: bool):

@@ -65,7 +65,7 @@ int small_launch(const double* d_apack, const double* dX, size_t ldx, double* dY
 
 // ---- on-chip rod pipeline for small grids (sri_rod_resident.hip, used by sri_rod.hip) -----------------------------
 struct ResidentRod;
-bool resident_supported(uint32_t m);                 // m = N - 1 <= 63 and m % 16 != 0
+bool resident_supported(uint32_t m);                 // 2 <= m = N - 1 <= 63
 // `device` must be current.  A_fine / w_fine / n_fine: this handle is the coarse start of an n_fine-node grid whose integration
 // operator is A_fine ((n_fine-1)^2, column-major) with initial-value weights w_fine — see coarse_view_of_fine_operator.
 int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, const double* A_fine = nullptr,

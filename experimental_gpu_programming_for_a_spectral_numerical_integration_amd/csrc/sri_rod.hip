@@ -288,7 +288,7 @@ struct sri_rod_handle {
   // host side of that loop, owned by the handle (no per-call allocation, nothing to leak on an error return):
   unsigned long long* h_state = nullptr;  // pinned, 2 slots x 4 words: the loop state read back per chunk
   hipEvent_t done[2] = {nullptr, nullptr};
-  sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64, (N-1) % 16 != 0), else null
+  sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64), else null
   bool use_resident = true;
   bool emit_position_rhs = false;         // set by sri_rod_integrate: the confirmation pass also writes b = R(q) e1 into d_B
   sri::ResidentRod* coarse = nullptr;     // N > 64: on-chip solver on a 32-node grid, predictor of the fine fixed point

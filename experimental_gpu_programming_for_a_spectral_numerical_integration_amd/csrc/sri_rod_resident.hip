@@ -17,7 +17,8 @@
 // one node and 1/2 A(K) q is in-lane arithmetic; the 16-byte pieces of an image row are XOR-swizzled by
 // (column >> 1) & 6 (conflict-free ds_read_b128 for that column order, tools/lds_bank_model.py); the initial-value term
 // rides in the product: the host packs -w = -Dn_NN^-1 Dn_IN as operator column k = m and the image holds the base
-// value of every column in slot k = m (needs a free slot: m % 16 != 0; other sizes use the streaming path).
+// value of every column in slot k = m (TM = m / 16 + 1 row tiles, so that slot always exists: m = 16, 32, 48 — the grids
+// of 2^p + 1 nodes — pay one nearly empty tile row for it).
 // Waves of a workgroup share only the read-only operator: after one barrier they run independently.
 #include <hip/hip_runtime.h>
 
@@ -468,7 +469,7 @@ struct ResidentRod {
   uint32_t cap_blocks = 0;
 };
 
-bool resident_supported(uint32_t m) { return m >= 2 && m <= 63 && m % 16 != 0; }
+bool resident_supported(uint32_t m) { return m >= 2 && m <= 63; }
 
 template <int TM, int TN, int NW>
 static int resident_launch(ResidentRod* h, ResidentArgs args, hipStream_t stream, uint32_t* blocks_out) {

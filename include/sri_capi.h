@@ -167,7 +167,7 @@ typedef struct sri_rod_handle sri_rod_t;
 int sri_rod_create(sri_rod_t **out, uint32_t n, int device);
 int sri_rod_destroy(sri_rod_t *h);
 
-/* Small grids (N <= 64 with (N-1) % 16 != 0: N = 16, 32, 64, ...) are integrated by an on-chip kernel: one launch
+/* Small grids (3 <= N <= 64) are integrated by an on-chip kernel: one launch
  * runs the whole fixed point (and the position step) with the rod state resident in LDS.  enable = 0 forces the
  * streaming path (one fused launch per iteration) that larger grids use; SRI_EUNSUPPORTED if enabling is impossible. */
 int sri_rod_set_resident(sri_rod_t *h, int enable);
@@ -175,10 +175,10 @@ int sri_rod_set_resident(sri_rod_t *h, int enable);
 /* Grids of more than 16 nodes start the fixed point from a coarse-grid solution: the same rods on a 32-node Chebyshev grid
  * (N > 64: on-chip pipeline, then interpolated by a kernel) or on a 32- / 16-node grid inside the on-chip pipeline itself
  * (32 < N <= 64 / 16 < N <= 32), interpolated to the fine nodes.  The coarse solve uses the FINE grid's operator as the
- * coarse nodes see it, so the start is rounding noise away from the fine fixed point (one fine sweep at N = 64 ... 512).  The result is still the fixed point of the fine system, tested and
- * confirmed as without it; only the iteration count changes (*iters counts fine-grid iterations).  enable = 0 starts
- * from Q = q_init at every node instead; SRI_EUNSUPPORTED if enabling is impossible (N <= 16, or no coarser grid
- * fits: (N-1) % 16 == 0 below 65). */
+ * coarse nodes see it, so the start is rounding noise away from the fine fixed point (one fine sweep at N = 64 ... 512).
+ * The result is still the fixed point of the fine system, tested and confirmed as without it; only the iteration count
+ * changes (*iters counts fine-grid iterations).  enable = 0 starts from Q = q_init at every node instead;
+ * SRI_EUNSUPPORTED if enabling is impossible (N <= 16: nothing coarser). */
 int sri_rod_set_predictor(sri_rod_t *h, int enable);
 
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):

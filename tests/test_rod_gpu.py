@@ -167,7 +167,7 @@ def test_resident_and_streaming_paths_agree(sri):
     assert abs(rod.iterations - it_res) >= 3 and abs(rod.iterations - 22) <= 6   # plain start: the streaming path's count
     rod.set_predictor(True)
     rod.set_resident(False)
-    for n in (17, 65, 256):                                      # (N-1) % 16 == 0, or too large
+    for n in (65, 256):                                          # too large for LDS
         big = sri.RodIntegrator(n)
         with pytest.raises(sri.SriError) as e:
             big.set_resident(True)
@@ -289,12 +289,15 @@ def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rod
 
 @pytest.mark.parametrize("n,rods", [(17, 9), (33, 21), (65, 6), (97, 4)])
 def test_grids_without_a_free_k_slot(sri, oracle, n, rods):
-    """(N-1) % 16 == 0: no free slot in the last k chunk, so the initial-value term is an epilogue, the on-chip pipeline
-    does not apply and (N = 65, 97) the predictor feeds a streaming loop whose operator has no tail."""
+    """(N-1) % 16 == 0 on the STREAMING path: no free slot in the last k chunk, so the initial-value term is an epilogue,
+    and (N = 65, 97) the predictor feeds a streaming loop whose operator has no tail.  (The on-chip pipeline gives these
+    grids one more tile row instead: test_on_chip_pipeline_on_grids_of_2p_plus_1_nodes.)"""
     import torch
 
     qe = _qe_batch(rods, seed=100 + n)
     rod = sri.RodIntegrator(n)
+    if n <= 64:
+        rod.set_resident(False)
     q_init = np.array([0.6, 0.0, 0.0, 0.8])
     r_init = np.array([-1.0, 0.25, 3.0])
     Q, R = rod.integrate(torch.from_numpy(qe).cuda(), q_init=q_init, r_init=r_init)
@@ -303,6 +306,36 @@ def test_grids_without_a_free_k_slot(sri, oracle, n, rods):
     relq = np.linalg.norm(Q.cpu().numpy() - Qo) / np.linalg.norm(Qo)
     relr = np.linalg.norm(R.cpu().numpy() - Ro) / np.linalg.norm(Ro)
     assert relq <= 1e-12 and relr <= 1e-12, (relq, relr, rod.iterations)
+
+
+@pytest.mark.parametrize("n,rods", [(17, 300), (33, 1000), (49, 77)])
+def test_on_chip_pipeline_on_grids_of_2p_plus_1_nodes(sri, oracle, n, rods):
+    """N - 1 = 16, 32, 48 (grids of 2^p + 1 nodes): the on-chip pipeline takes one tile row more than the unknown nodes need,
+    so that the base value still has its slot k = N - 1.  Against the oracle, against the streaming path, coarse start on
+    and off."""
+    import torch
+
+    qe = _qe_batch(rods, seed=200 + n)
+    dqe = torch.from_numpy(qe).cuda()
+    q_init = np.array([0.6, 0.0, 0.0, 0.8])
+    r_init = np.array([-1.0, 0.25, 3.0])
+    rod = sri.RodIntegrator(n)
+    Qa, Ra = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_a = rod.iterations
+    rod.set_predictor(False)
+    Qb, Rb = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    it_b = rod.iterations
+    rod.set_resident(False)
+    Qc, Rc = rod.integrate(dqe, q_init=q_init, r_init=r_init)
+    torch.cuda.synchronize()
+    assert it_a < it_b
+    for Q, R in ((Qb, Rb), (Qc, Rc)):
+        assert (Qa - Q).abs().max().item() <= 1e-13 and (Ra - R).abs().max().item() <= 1e-13
+    sample = slice(0, 16)
+    Qo, Ro = _oracle_rods(oracle, n, qe[sample], q_init, r_init)
+    relq = np.linalg.norm(Qa[sample].cpu().numpy() - Qo) / np.linalg.norm(Qo)
+    relr = np.linalg.norm(Ra[sample].cpu().numpy() - Ro) / np.linalg.norm(Ro)
+    assert relq <= 1e-12 and relr <= 1e-12, (relq, relr)
 
 
 @pytest.mark.parametrize("n,scale", [(16, 6.0), (64, 8.0), (129, 8.0)])

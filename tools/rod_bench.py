@@ -47,8 +47,8 @@ def main():
     n, rods, m = args.n, args.rods, args.n - 1
     dev = torch.device("cuda", 0)
     rod = sri.RodIntegrator(n)
-    resident = m <= 63 and m % 16 != 0 and not args.streaming
-    if m <= 63 and m % 16 != 0:
+    resident = m <= 63 and not args.streaming
+    if m <= 63:
         rod.set_resident(resident)
     coarse_start = not args.no_coarse_start
     try:
