@@ -337,6 +337,8 @@ struct RodDeviceGuard {
 
 extern "C" {
 
+static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply_t* integ);
+
 int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   if (out == nullptr || n < 3) return SRI_EINVAL;
   *out = nullptr;
@@ -353,6 +355,22 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   h->m = n - 1;
   h->ldw = (static_cast<size_t>(n - 1) + 15) & ~static_cast<size_t>(15);
   h->integ = integ;
+  try {                                                         // (host vectors below: no exception may cross the C ABI)
+    rc = rod_create_parts(h, n, device, integ);
+  } catch (const std::bad_alloc&) {
+    rc = SRI_ENOMEM;
+  }
+  if (rc != SRI_OK) {
+    sri_rod_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SRI_OK;
+}
+
+// everything of a rod handle beyond the integration apply; on failure the caller destroys `h`
+static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply_t* integ) {
+  int rc = SRI_OK;
   std::vector<double> x(n);
   sri::cheb_points(n, 1.0, x.data());
   // P1 per unknown node, same operations as strain_kernel (this file is compiled with -ffp-contract=off)
@@ -369,18 +387,15 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
       hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[1], hipEventDisableTiming) != hipSuccess) {
-    sri_rod_destroy(h);
     return SRI_ENOMEM;
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-    sri_rod_destroy(h);
     return SRI_EHIP;
   }
   if (sri::resident_supported(h->m)) {
     rc = sri::resident_create(n, device, prop.multiProcessorCount, &h->resident);
     if (rc != SRI_OK) {
-      sri_rod_destroy(h);
       return rc;
     }
   } else if (n > 64) {
@@ -393,24 +408,20 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
     if (rc == SRI_OK)
       rc = sri::resident_create(sri::kCoarseN, device, prop.multiProcessorCount, &h->coarse, A_fine.data(), w_fine.data(), n);
     if (rc != SRI_OK) {
-      sri_rod_destroy(h);
       return rc;
     }
     std::vector<double> P(static_cast<size_t>(n) * sri::kCoarseN), PT(static_cast<size_t>(sri::kCoarseN) * h->m, 0.0);
     rc = sri::cheb_interp(sri::kCoarseN, n, P.data(), n);
     if (rc != SRI_OK) {
-      sri_rod_destroy(h);
       return rc;
     }
     for (uint32_t i = 0; i < h->m; ++i)                          // unknown nodes only, transposed for coalesced reads
       for (int j = 0; j < sri::kCoarseN; ++j) PT[static_cast<size_t>(j) * h->m + i] = P[i + static_cast<size_t>(j) * n];
     if (hipMalloc(&h->d_PT, PT.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(h->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-      sri_rod_destroy(h);
       return SRI_ENOMEM;
     }
   }
-  *out = h;
   return SRI_OK;
 }
 

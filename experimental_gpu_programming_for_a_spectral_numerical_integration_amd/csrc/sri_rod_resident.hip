@@ -577,13 +577,31 @@ static int coarse_view_of_fine_operator(const double* A_f, const double* w_f, ui
   return SRI_OK;
 }
 
+static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num_cus, const double* A_fine, const double* w_fine, uint32_t n_fine);
+
 // Caller has made `device` current.
 int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, const double* A_fine, const double* w_fine, uint32_t n_fine) {
   *out = nullptr;
-  const uint32_t m = n - 1;
-  if (!resident_supported(m)) return SRI_EUNSUPPORTED;
+  if (!resident_supported(n - 1)) return SRI_EUNSUPPORTED;
   ResidentRod* h = new (std::nothrow) ResidentRod();
   if (h == nullptr) return SRI_ENOMEM;
+  int rc;
+  try {                                                         // (host vectors: no exception may reach the C ABI above)
+    rc = resident_create_parts(h, n, device, num_cus, A_fine, w_fine, n_fine);
+  } catch (const std::bad_alloc&) {
+    rc = SRI_ENOMEM;
+  }
+  if (rc != SRI_OK) {
+    resident_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SRI_OK;
+}
+
+// on failure the caller destroys `h`
+static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num_cus, const double* A_fine, const double* w_fine, uint32_t n_fine) {
+  const uint32_t m = n - 1;
   h->device = device;
   h->n = n;
   h->m = m;
@@ -592,12 +610,12 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, cons
   const int TM = h->tm;
   std::vector<double> A(static_cast<size_t>(m) * m), Din(m), w(m, 0.0), x(n);
   int rc = cheb_integration(n, A.data(), m, Din.data());
-  if (rc != SRI_OK) { delete h; return rc; }
+  if (rc != SRI_OK) return rc;
   for (uint32_t k = 0; k < m; ++k)
     for (uint32_t i = 0; i < m; ++i) w[i] = w[i] + A[i + static_cast<size_t>(k) * m] * Din[k];   // as sri_apply_create
   if (A_fine != nullptr && w_fine != nullptr && n_fine > n) {    // this handle starts the fixed point of an n_fine-node grid
     rc = coarse_view_of_fine_operator(A_fine, w_fine, n_fine, n, A, w);
-    if (rc != SRI_OK) { delete h; return rc; }
+    if (rc != SRI_OK) return rc;
   }
   cheb_points(n, 1.0, x.data());
   std::vector<double> packed(static_cast<size_t>(TM) * TM * 256, 0.0), p1(static_cast<size_t>(TM) * 16, 0.0);
@@ -614,7 +632,7 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, cons
           }
   for (uint32_t i = 0; i < m; ++i) p1[i] = (2 * x[i] - (1.0 + 0.0)) / (1.0 - 0.0);
   h->cap_blocks = static_cast<uint32_t>(num_cus) * 16u;
-  auto fail = [&](int code) { resident_destroy(h); return code; };
+  auto fail = [&](int code) { return code; };
   if (hipMalloc(&h->d_apack, packed.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
   if (hipMalloc(&h->d_p1, p1.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
   if (hipMalloc(&h->d_stats, 2 * sizeof(double) * h->cap_blocks) != hipSuccess) return fail(SRI_ENOMEM);
@@ -659,7 +677,6 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, cons
     if (hipMemcpy(h->d_cpack, cpack.data(), cpack.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
     if (hipMemcpy(h->d_p1c, p1c.data(), p1c.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   }
-  *out = h;
   return SRI_OK;
 }
 
