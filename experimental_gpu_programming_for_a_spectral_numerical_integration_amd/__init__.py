@@ -42,6 +42,7 @@ C_ABI = {
     "sri_cheb_integration": (_int, [_u32, _dp, _sz, _dp]),
     "sri_ivp": (_int, [_u32, _u32, _dp, _dp, _dp, _sz]),
     "sri_cheb_interp": (_int, [_u32, _u32, _dp, _sz]),
+    "sri_cheb_coarse_view": (_int, [_u32, _dp, _sz, _dp, _u32, _dp, _sz, _dp]),
     "sri_apply_create": (_int, [C.POINTER(_vp), _u32, _int, _int]),
     "sri_apply_create_matrix": (_int, [C.POINTER(_vp), _u32, _dp, _sz, _int]),
     "sri_apply_set_max_workgroups": (_int, [_vp, _u32]),
@@ -204,6 +205,20 @@ def cheb_interp(n_from: int, n_to: int) -> np.ndarray:
     P = _fmat(n_to, n_from)
     _chk(load_library().sri_cheb_interp(n_from, n_to, _p(P), n_to), "sri_cheb_interp")
     return P
+
+
+def cheb_coarse_view(A_fine: np.ndarray, w_fine: np.ndarray, n_coarse: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(A_coarse, w_coarse): the integration operator ``A_fine`` ((n_fine-1)^2) and its initial-value weights as a grid of
+    ``n_coarse`` nodes sees them (sri_cheb_coarse_view) — what the rod predictor's coarse solve runs on."""
+    A_fine = np.asfortranarray(A_fine, dtype=np.float64)
+    w_fine = np.ascontiguousarray(w_fine, dtype=np.float64)
+    n_fine = A_fine.shape[0] + 1
+    if A_fine.shape != (n_fine - 1, n_fine - 1) or w_fine.shape != (n_fine - 1,):
+        raise ValueError("A_fine must be (n_fine-1, n_fine-1) and w_fine (n_fine-1,)")
+    Ac, wc = _fmat(n_coarse - 1, n_coarse - 1), np.zeros(n_coarse - 1)
+    _chk(load_library().sri_cheb_coarse_view(n_fine, _p(A_fine), n_fine - 1, _p(w_fine), n_coarse, _p(Ac), n_coarse - 1, _p(wc)),
+         "sri_cheb_coarse_view")
+    return Ac, wc
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1675,10 +1675,9 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     return fail(SRI_EHIP);
   if (w_host != nullptr) {
     const size_t padded = static_cast<size_t>(h->row_blocks) * h->bm;
-    std::vector<double> w(padded, 0.0);
-    std::memcpy(w.data(), w_host, sizeof(double) * rows);
     if (hipMalloc(&h->d_w, padded * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
-    if (hipMemcpy(h->d_w, w.data(), padded * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+    if (hipMemset(h->d_w, 0, padded * sizeof(double)) != hipSuccess) return fail(SRI_EHIP);                  // (zero padding)
+    if (hipMemcpy(h->d_w, w_host, rows * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   }
   *out = h;
   return SRI_OK;

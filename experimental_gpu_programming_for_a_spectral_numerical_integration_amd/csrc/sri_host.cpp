@@ -164,8 +164,9 @@ int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double*
 // on a row whose node coincides with a coarse node.  Accumulated in long double, rounded once.
 int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld) {
   if (n_from < 2 || n_to < 2 || P == nullptr || ld < n_to) return SRI_EINVAL;
-  std::vector<double> xc(n_from), xf(n_to);
-  std::vector<long double> t(n_from);
+  std::vector<double> xc, xf;
+  std::vector<long double> t;
+  try { xc.resize(n_from); xf.resize(n_to); t.resize(n_from); } catch (const std::bad_alloc&) { return SRI_ENOMEM; }
   cheb_points(n_from, 1.0, xc.data());
   cheb_points(n_to, 1.0, xf.data());
   for (uint32_t i = 0; i < n_to; ++i) {
@@ -181,6 +182,70 @@ int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld) {
     for (uint32_t j = 0; j < n_from; ++j)
       P[i + static_cast<size_t>(j) * ld] = hit >= 0 ? (static_cast<int>(j) == hit ? 1.0 : 0.0) : static_cast<double>(t[j] / denom);
   }
+  return SRI_OK;
+}
+
+// The integration operator a COARSE grid should use when its solution only starts the fixed point of a fine grid.
+// In exact arithmetic Dn_NN^-1 integrates polynomials exactly on either grid and -Dn_NN^-1 Dn_IN is the vector of ones (a
+// differentiation matrix annihilates constants).  As computed, both are off by the conditioning of the inverse — 2e-14 on a
+// 256-node grid, 8e-14 on 1024 nodes — SMOOTHLY along the rod and differently on every grid.  The fine fixed point contains
+// the fine grid's deviation; a start that contains the coarse grid's instead is a smooth ~1e-14 away from it, which
+// restarted Picard iteration removes at L/(k+1) per sweep (five or six sweeps to get under 1e-14), while the rounding noise
+// proper is damped by the first sweep.  So the coarse solve uses the FINE operator seen from its own nodes:
+//   A_c = R_u A_f P~            u_c = R [-w_f ; 1]   (returned as w_c = -u_c)
+// R: fine nodes -> coarse nodes (base node last on both grids, sri_cheb_interp), R_u its columns of unknown fine nodes;
+// P~: the n_c - 1 unknown coarse nodes -> the unknown fine nodes (the right-hand side has no value at the base node),
+// barycentric with weights 1 / prod (x_j - x_k).  Host, long double accumulation, once per handle (may throw std::bad_alloc: callers contain it).
+int coarse_view_of_fine_operator(const double* A_f, size_t lda, const double* w_f, uint32_t n_f, uint32_t n_c, std::vector<double>& A_c,
+                                 std::vector<double>& w_c) {
+  if (A_f == nullptr || w_f == nullptr || n_c < 3 || n_f <= n_c || lda < n_f - 1) return SRI_EINVAL;
+  const uint32_t m_f = n_f - 1, m_c = n_c - 1;
+  std::vector<double> R(static_cast<size_t>(n_c) * n_f), xc(n_c), xf(n_f);
+  int rc = cheb_interp(n_f, n_c, R.data(), n_c);
+  if (rc != SRI_OK) return rc;
+  cheb_points(n_c, 1.0, xc.data());
+  cheb_points(n_f, 1.0, xf.data());
+  w_c.assign(m_c, 0.0);
+  for (uint32_t i = 0; i < m_c; ++i) {
+    long double s = 0.0L;
+    for (uint32_t j = 0; j < n_f; ++j)
+      s += static_cast<long double>(R[i + static_cast<size_t>(j) * n_c]) * (j < m_f ? -static_cast<long double>(w_f[j]) : 1.0L);
+    w_c[i] = -static_cast<double>(s);
+  }
+  std::vector<long double> bw(m_c), P(static_cast<size_t>(m_f) * m_c), t(m_c);
+  for (uint32_t j = 0; j < m_c; ++j) {
+    long double prod = 1.0L;
+    for (uint32_t k = 0; k < m_c; ++k)
+      if (k != j) prod *= static_cast<long double>(xc[j]) - static_cast<long double>(xc[k]);
+    bw[j] = 1.0L / prod;
+  }
+  for (uint32_t i = 0; i < m_f; ++i) {
+    int hit = -1;
+    long double denom = 0.0L;
+    for (uint32_t j = 0; j < m_c; ++j) {
+      const long double d = static_cast<long double>(xf[i]) - static_cast<long double>(xc[j]);
+      if (d == 0.0L) { hit = static_cast<int>(j); break; }
+      t[j] = bw[j] / d;
+      denom += t[j];
+    }
+    for (uint32_t j = 0; j < m_c; ++j)
+      P[i + static_cast<size_t>(j) * m_f] = hit >= 0 ? (static_cast<int>(j) == hit ? 1.0L : 0.0L) : t[j] / denom;
+  }
+  std::vector<long double> AP(static_cast<size_t>(m_f) * m_c, 0.0L);             // A_f P~
+  for (uint32_t j = 0; j < m_c; ++j)
+    for (uint32_t k = 0; k < m_f; ++k) {
+      const long double pkj = P[k + static_cast<size_t>(j) * m_f];
+      const double* col = A_f + static_cast<size_t>(k) * lda;
+      long double* out = AP.data() + static_cast<size_t>(j) * m_f;
+      for (uint32_t i = 0; i < m_f; ++i) out[i] += static_cast<long double>(col[i]) * pkj;
+    }
+  A_c.assign(static_cast<size_t>(m_c) * m_c, 0.0);
+  for (uint32_t j = 0; j < m_c; ++j)
+    for (uint32_t i = 0; i < m_c; ++i) {
+      long double s = 0.0L;
+      for (uint32_t k = 0; k < m_f; ++k) s += static_cast<long double>(R[i + static_cast<size_t>(k) * n_c]) * AP[k + static_cast<size_t>(j) * m_f];
+      A_c[i + static_cast<size_t>(j) * m_c] = static_cast<double>(s);
+    }
   return SRI_OK;
 }
 
@@ -205,6 +270,22 @@ int sri_ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, dou
 }
 
 int sri_cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld) { return sri::cheb_interp(n_from, n_to, P, ld); }
+int sri_cheb_coarse_view(uint32_t n_fine, const double* A_fine, size_t lda, const double* w_fine, uint32_t n_coarse, double* A_coarse,
+                         size_t ldc, double* w_coarse) {
+  if (A_coarse == nullptr || w_coarse == nullptr || n_coarse < 3 || ldc < n_coarse - 1) return SRI_EINVAL;
+  try {
+    std::vector<double> A, w;
+    const int rc = sri::coarse_view_of_fine_operator(A_fine, lda, w_fine, n_fine, n_coarse, A, w);
+    if (rc != SRI_OK) return rc;
+    const uint32_t mc = n_coarse - 1;
+    for (uint32_t j = 0; j < mc; ++j)
+      for (uint32_t i = 0; i < mc; ++i) A_coarse[i + static_cast<size_t>(j) * ldc] = A[i + static_cast<size_t>(j) * mc];
+    for (uint32_t i = 0; i < mc; ++i) w_coarse[i] = w[i];
+    return SRI_OK;
+  } catch (const std::bad_alloc&) {
+    return SRI_ENOMEM;
+  }
+}
 
 const char* sri_strerror(int status) {
   switch (status) {

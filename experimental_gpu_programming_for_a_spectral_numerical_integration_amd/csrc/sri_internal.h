@@ -19,6 +19,9 @@ int dense_inverse(uint32_t m, const double* A, size_t lda, double* Ainv, size_t 
 int cheb_integration(uint32_t n, double* Dnn_inv, size_t ld, double* Din);
 int ivp(uint32_t m, uint32_t s, const double* Din, const double* x_base, double* out, size_t ld);
 int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld);
+// the fine integration operator (and its initial-value weights) as a coarser grid sees it — sri_host.cpp; may throw bad_alloc
+int coarse_view_of_fine_operator(const double* A_f, size_t lda, const double* w_f, uint32_t n_f, uint32_t n_c, std::vector<double>& A_c,
+                                 std::vector<double>& w_c);
 
 // ---- error bookkeeping (sri_apply.hip): what sri_last_hip_error() reports -----------------------
 void record_hip_error(int hip_error);

@@ -514,69 +514,6 @@ int resident_destroy(ResidentRod* h) {
   return SRI_OK;
 }
 
-// The integration operator a COARSE grid should use when its solution only starts the fixed point of a fine grid.
-// In exact arithmetic Dn_NN^-1 integrates polynomials exactly on either grid and -Dn_NN^-1 Dn_IN is the vector of ones (a
-// differentiation matrix annihilates constants).  As computed, both are off by the conditioning of the inverse — 2e-14 on a
-// 256-node grid, 8e-14 on 1024 nodes — SMOOTHLY along the rod and differently on every grid.  The fine fixed point contains
-// the fine grid's deviation; a start that contains the coarse grid's instead is a smooth ~1e-14 away from it, which
-// restarted Picard iteration removes at L/(k+1) per sweep (five or six sweeps to get under 1e-14), while the rounding noise
-// proper is damped by the first sweep.  So the coarse solve uses the FINE operator seen from its own nodes:
-//   A_c = R_u A_f P~            u_c = R [-w_f ; 1]   (returned as w_c = -u_c)
-// R: fine nodes -> coarse nodes (base node last on both grids, sri_cheb_interp), R_u its columns of unknown fine nodes;
-// P~: the n_c - 1 unknown coarse nodes -> the unknown fine nodes (the right-hand side has no value at the base node),
-// barycentric with weights 1 / prod (x_j - x_k).  Host, long double accumulation, once per handle.
-static int coarse_view_of_fine_operator(const double* A_f, const double* w_f, uint32_t n_f, uint32_t n_c, std::vector<double>& A_c,
-                                        std::vector<double>& w_c) {
-  const uint32_t m_f = n_f - 1, m_c = n_c - 1;
-  std::vector<double> R(static_cast<size_t>(n_c) * n_f), xc(n_c), xf(n_f);
-  int rc = cheb_interp(n_f, n_c, R.data(), n_c);
-  if (rc != SRI_OK) return rc;
-  cheb_points(n_c, 1.0, xc.data());
-  cheb_points(n_f, 1.0, xf.data());
-  w_c.assign(m_c, 0.0);
-  for (uint32_t i = 0; i < m_c; ++i) {
-    long double s = 0.0L;
-    for (uint32_t j = 0; j < n_f; ++j)
-      s += static_cast<long double>(R[i + static_cast<size_t>(j) * n_c]) * (j < m_f ? -static_cast<long double>(w_f[j]) : 1.0L);
-    w_c[i] = -static_cast<double>(s);
-  }
-  std::vector<long double> bw(m_c), P(static_cast<size_t>(m_f) * m_c), t(m_c);
-  for (uint32_t j = 0; j < m_c; ++j) {
-    long double prod = 1.0L;
-    for (uint32_t k = 0; k < m_c; ++k)
-      if (k != j) prod *= static_cast<long double>(xc[j]) - static_cast<long double>(xc[k]);
-    bw[j] = 1.0L / prod;
-  }
-  for (uint32_t i = 0; i < m_f; ++i) {
-    int hit = -1;
-    long double denom = 0.0L;
-    for (uint32_t j = 0; j < m_c; ++j) {
-      const long double d = static_cast<long double>(xf[i]) - static_cast<long double>(xc[j]);
-      if (d == 0.0L) { hit = static_cast<int>(j); break; }
-      t[j] = bw[j] / d;
-      denom += t[j];
-    }
-    for (uint32_t j = 0; j < m_c; ++j)
-      P[i + static_cast<size_t>(j) * m_f] = hit >= 0 ? (static_cast<int>(j) == hit ? 1.0L : 0.0L) : t[j] / denom;
-  }
-  std::vector<long double> AP(static_cast<size_t>(m_f) * m_c, 0.0L);             // A_f P~
-  for (uint32_t j = 0; j < m_c; ++j)
-    for (uint32_t k = 0; k < m_f; ++k) {
-      const long double pkj = P[k + static_cast<size_t>(j) * m_f];
-      const double* col = A_f + static_cast<size_t>(k) * m_f;
-      long double* out = AP.data() + static_cast<size_t>(j) * m_f;
-      for (uint32_t i = 0; i < m_f; ++i) out[i] += static_cast<long double>(col[i]) * pkj;
-    }
-  A_c.assign(static_cast<size_t>(m_c) * m_c, 0.0);
-  for (uint32_t j = 0; j < m_c; ++j)
-    for (uint32_t i = 0; i < m_c; ++i) {
-      long double s = 0.0L;
-      for (uint32_t k = 0; k < m_f; ++k) s += static_cast<long double>(R[i + static_cast<size_t>(k) * n_c]) * AP[k + static_cast<size_t>(j) * m_f];
-      A_c[i + static_cast<size_t>(j) * m_c] = static_cast<double>(s);
-    }
-  return SRI_OK;
-}
-
 static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num_cus, const double* A_fine, const double* w_fine, uint32_t n_fine);
 
 // Caller has made `device` current.
@@ -614,7 +551,7 @@ static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num
   for (uint32_t k = 0; k < m; ++k)
     for (uint32_t i = 0; i < m; ++i) w[i] = w[i] + A[i + static_cast<size_t>(k) * m] * Din[k];   // as sri_apply_create
   if (A_fine != nullptr && w_fine != nullptr && n_fine > n) {    // this handle starts the fixed point of an n_fine-node grid
-    rc = coarse_view_of_fine_operator(A_fine, w_fine, n_fine, n, A, w);
+    rc = coarse_view_of_fine_operator(A_fine, n_fine - 1, w_fine, n_fine, n, A, w);
     if (rc != SRI_OK) return rc;
   }
   cheb_points(n, 1.0, x.data());
@@ -648,7 +585,7 @@ static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num
     const int TMC = TM >= 3 ? 2 : 1;
     const uint32_t nc = 16u * TMC, mc = nc - 1;
     std::vector<double> Ac, wc, xc(nc), Pm(static_cast<size_t>(n) * nc);
-    rc = coarse_view_of_fine_operator(A.data(), w.data(), n, nc, Ac, wc);   // what the fine loop will apply, at the coarse nodes
+    rc = coarse_view_of_fine_operator(A.data(), m, w.data(), n, nc, Ac, wc);   // what the fine loop will apply, at the coarse nodes
     if (rc == SRI_OK) rc = cheb_interp(nc, n, Pm.data(), n);
     if (rc != SRI_OK) return fail(rc);
     cheb_points(nc, 1.0, xc.data());

@@ -88,6 +88,16 @@ int sri_ivp(uint32_t m, uint32_t s, const double *Din, const double *x_base, dou
  * values at the n_to nodes.  sri_rod_* uses it to start the fixed point of a fine grid from a 32-node solution. */
 int sri_cheb_interp(uint32_t n_from, uint32_t n_to, double *P, size_t ld);
 
+/* Not in the reference: the integration operator of a FINE grid (A_fine = Dn_NN^-1 of n_fine nodes, (n_fine-1)^2 column-major,
+ * lda >= n_fine - 1; w_fine = Dn_NN^-1 Dn_IN) as a coarser grid of n_coarse < n_fine nodes sees it:
+ *   A_coarse = R_u A_fine P~   ((n_coarse-1)^2, ldc >= n_coarse - 1),     w_coarse = -R [-w_fine ; 1]
+ * with R the fine->coarse interpolation of sri_cheb_interp (base node last), R_u its columns of unknown fine nodes and P~ the
+ * interpolation from the unknown coarse nodes to the unknown fine nodes.  In exact arithmetic this IS the coarse grid's own
+ * operator; as computed it carries the fine grid's rounding-level deviation instead of the coarse grid's, which is what a
+ * coarse solve needs when it only starts the fixed point of the fine grid (sri_rod_*: one fine sweep instead of six). */
+int sri_cheb_coarse_view(uint32_t n_fine, const double *A_fine, size_t lda, const double *w_fine, uint32_t n_coarse,
+                         double *A_coarse, size_t ldc, double *w_coarse);
+
 /* ---------------------------------------------------------------------------------------- */
 /* The apply:  Y[rows x M] = A[rows x rows] * X[rows x M]   (main.cpp:172; Kronecker form      */
 /* main.cpp:97).  A is formed on the host once, packed into MFMA-fragment order and kept on    */

@@ -150,6 +150,47 @@ def test_chebyshev_interpolation_matrix(sri, n_from, n_to):
     assert P[0, 0] == 1.0 and P[-1, -1] == 1.0                   # both grids share the end points X = 1 and X = 0
 
 
+@pytest.mark.parametrize("n_fine,n_coarse", [(256, 32), (64, 32), (33, 16), (128, 32), (20, 16)])
+def test_coarse_view_of_the_fine_integration_operator(sri, n_fine, n_coarse):
+    """sri_cheb_coarse_view (host former behind the rod predictor's coarse solve): A_c = R_u A_f P~, w_c = -R[-w_f; 1].
+    (a) an independent numpy evaluation of the same triple product; (b) in exact arithmetic it IS the coarse grid's own
+    Dn_NN^-1 — so it differs from that only at rounding level; (c) it integrates polynomials like the fine operator does;
+    (d) the point of it: restricted to the coarse nodes, the FINE operator's deviation from exactness (w_f + 1, the
+    ~1e-14 by which -Dn_NN^-1 Dn_IN misses the vector of ones) is reproduced, which the coarse grid's own w_c is not."""
+    Af, Dinf = sri.integration_matrix(n_fine)
+    wf = Af @ Dinf
+    Ac, wc = sri.cheb_coarse_view(Af, wf, n_coarse)
+    mf, mc = n_fine - 1, n_coarse - 1
+    assert Ac.shape == (mc, mc) and wc.shape == (mc,)
+    # (a) numpy: R from sri_cheb_interp; P~ barycentric on the unknown coarse nodes with weights 1 / prod (x_j - x_k)
+    xf, xc = sri.ComputeChebyshevPoints(n_fine), sri.ComputeChebyshevPoints(n_coarse)
+    R = sri.cheb_interp(n_fine, n_coarse)
+    xs = xc[:mc].astype(np.longdouble)
+    bw = np.array([1.0 / np.prod([xs[j] - xs[k] for k in range(mc) if k != j]) for j in range(mc)], dtype=np.longdouble)
+    Pt = np.zeros((mf, mc))
+    for i in range(mf):
+        d = np.longdouble(xf[i]) - xs
+        if (d == 0).any():
+            Pt[i, int(np.argmax(d == 0))] = 1.0
+        else:
+            t = bw / d
+            Pt[i] = (t / t.sum()).astype(np.float64)
+    ref = R[:mc, :mf] @ Af @ Pt
+    assert np.abs(Ac - ref).max() <= 5e-15
+    assert np.abs(wc + R[:mc] @ np.concatenate([-wf, [1.0]])).max() <= 2e-15
+    # (b) the coarse grid's own operator, at rounding level
+    Ac_own, Dinc = sri.integration_matrix(n_coarse)
+    assert np.abs(Ac - Ac_own).max() <= 2e-14
+    # (c) integrates polynomials from the base node X = 0: A_c (d/dX X^p) = X^p at the unknown coarse nodes
+    for p_ in (1, 2, 5):
+        assert np.abs(Ac @ (p_ * xc[:mc] ** (p_ - 1)) - xc[:mc] ** p_).max() <= 3e-14, p_
+    # (d) carries the FINE grid's initial-value deviation to the coarse nodes
+    dev_fine_at_coarse = R[:mc] @ np.concatenate([wf + 1.0, [0.0]])
+    assert np.abs((wc + 1.0) - dev_fine_at_coarse).max() <= 2e-15
+    lib = sri.load_library()
+    assert lib.sri_cheb_coarse_view(n_coarse, None, 0, None, n_coarse, None, 0, None) == -1      # SRI_EINVAL
+
+
 def test_comm_entry_points_validate_without_a_gpu(sri):
     """sri_comm_* (csrc/sri_comm.hip): argument errors first, then SRI_ENODEVICE on a box without a GPU — never a crash,
     and RCCL is not even loaded for it."""
