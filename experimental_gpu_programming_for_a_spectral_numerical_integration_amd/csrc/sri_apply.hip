@@ -1890,8 +1890,17 @@ struct HostPipe {
   double* dY[SLOTS] = {};
   double* dB = nullptr;
   size_t slot_doubles = 0, base_doubles = 0;
+  // pinned, library-owned: the head and tail fragments (< one page each) of X, x_base and Y that lie outside the pages
+  // page-locked in the caller's buffers (PinRegistry) pass through here, so that no pageable transfer sits in the pipeline
+  static constexpr size_t FRAG = 4096;
+  char* frag = nullptr;                                         // 6 x FRAG: X head, X tail, x_base head, x_base tail, Y head, Y tail
 
   int reserve(size_t doubles_per_slot, size_t base) {
+    if (frag == nullptr && hipHostMalloc(reinterpret_cast<void**>(&frag), 6 * FRAG, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      frag = nullptr;
+      return SRI_ENOMEM;
+    }
     if (s_in == nullptr) {
       SRI_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
       SRI_HIP(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking));
@@ -1939,49 +1948,55 @@ struct HostPipe {
       if (returned[i]) (void)hipEventDestroy(returned[i]);
     }
     if (dB) (void)hipFree(dB);
+    if (frag) (void)hipHostFree(frag);
     if (s_in) (void)hipStreamDestroy(s_in);
     if (s_run) (void)hipStreamDestroy(s_run);
     if (s_out) (void)hipStreamDestroy(s_out);
   }
 };
 
-// Page-locks [ptr, ptr + bytes) for the lifetime of the object — through a process-wide registry, because registrations
-// are page-granular and do not nest: two handles (one host thread per GPU is the documented sharding) working on adjacent
-// column slabs of ONE host buffer share a boundary page, or share a read-only X outright, and the call that finishes
-// first must not unregister pages the other call's asynchronous copies still use.  The registry keeps the page-aligned
-// ranges THIS library registered, with reference counts: a request that lies inside a registered range shares it; one
-// that merely overlaps a registered range, or a range the caller (or anyone else) registered, or that cannot be locked,
-// is not pinned at all — the copies then take HIP's pageable path: slower, same stream program, same result.  Small
-// buffers are not pinned either (they share heap pages with their neighbours and gain nothing).
+// Page-locks the caller's host panel for the lifetime of the object — through a process-wide registry, and only the pages that
+// lie WHOLLY inside [ptr, ptr + bytes).  Registrations are page-granular and do not nest; two handles (one host thread per GPU
+// is the documented sharding) working on adjacent column slabs of ONE host buffer, or X and Y of one call that the allocator
+// placed back to back, share a boundary page.  With interior pages only, the registered ranges of distinct buffers never touch,
+// so every panel of a megabyte or more is pinned, whatever its neighbours are; the head and tail fragments (< 4 KiB each) go
+// as separate small copies, which HIP stages through its own buffers (copy_split in run_host).  A request whose interior lies
+// inside a registered range shares it (reference counts: a read-only X used by several threads); one that partially overlaps a
+// registered range, or pages the caller (or anyone else) registered, or that cannot be locked, is not pinned at all — the copies
+// then take HIP's pageable path: slower, same stream program, same result.  What this design avoids on purpose: large
+// PAGEABLE transfers next to registered ranges — HIP pins such buffers on the fly and remembers the pins by address, and
+// two GPU memory faults on host-heap addresses in round 3's test runs point at that mixture.
 class PinRegistry {
  public:
   static PinRegistry& instance() {
     static PinRegistry r;
     return r;
   }
-  // returns an id > 0 to pass to release(), or 0 if the range is not pinned by this library
-  size_t acquire(const void* p, size_t bytes) {
+  // returns an id > 0 to pass to release() and the registered byte range [*ilo, *ihi), or 0 if nothing was pinned
+  size_t acquire(const void* p, size_t bytes, uintptr_t* ilo_out, uintptr_t* ihi_out) {
+    *ilo_out = *ihi_out = 0;
     if (p == nullptr || bytes < kMinBytes) return 0;
     const uintptr_t page = 4096;
     const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
-    const uintptr_t plo = lo & ~(page - 1), phi = (hi + page - 1) & ~(page - 1);       // the pages the range touches
+    const uintptr_t ilo = (lo + page - 1) & ~(page - 1), ihi = hi & ~(page - 1);          // the pages wholly inside
+    if (ihi <= ilo || ihi - ilo < kMinBytes / 2) return 0;
     std::lock_guard<std::mutex> lock(mutex_);
     for (Entry& e : entries_) {
-      if (lo >= e.lo && hi <= e.hi) { ++e.refs; return e.id; }          // inside a range we hold: share it
-      if (plo < e.phi && e.plo < phi) return 0;                         // shares a PAGE with one: cannot be locked twice
+      if (ilo >= e.lo && ihi <= e.hi) { ++e.refs; *ilo_out = ilo; *ihi_out = ihi; return e.id; }   // inside a range we hold: share it
+      if (ilo < e.hi && e.lo < ihi) return 0;                           // genuinely overlapping buffers: leave it to HIP
     }
-    // the registration itself is the exact range (HIP looks a pointer up by containment: a neighbour that merely shares
-    // our first or last page stays "pageable" for it, as it must)
-    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+    if (hipHostRegister(reinterpret_cast<void*>(ilo), ihi - ilo, hipHostRegisterDefault) != hipSuccess) {
       (void)hipGetLastError();                                          // the caller's own registration, or not lockable
       return 0;
     }
     try {
-      entries_.push_back(Entry{lo, hi, plo, phi, 1, ++next_id_});
+      entries_.push_back(Entry{ilo, ihi, 1, ++next_id_});
     } catch (const std::bad_alloc&) {
-      (void)hipHostUnregister(const_cast<void*>(p));
+      (void)hipHostUnregister(reinterpret_cast<void*>(ilo));
       return 0;
     }
+    *ilo_out = ilo;
+    *ihi_out = ihi;
     return next_id_;
   }
   void release(size_t id) {
@@ -1999,7 +2014,7 @@ class PinRegistry {
   static constexpr size_t kMinBytes = size_t(1) << 20;
 
  private:
-  struct Entry { uintptr_t lo, hi, plo, phi; int refs; size_t id; };
+  struct Entry { uintptr_t lo, hi; int refs; size_t id; };    // registered (page-aligned) byte range
   std::mutex mutex_;
   std::vector<Entry> entries_;
   size_t next_id_ = 0;
@@ -2007,11 +2022,63 @@ class PinRegistry {
 
 struct PinnedRange {
   size_t id = 0;
-  PinnedRange(const void* p, size_t bytes) : id(PinRegistry::instance().acquire(p, bytes)) {}
+  uintptr_t ilo = 0, ihi = 0;                                   // the pinned part of the buffer (empty if id == 0)
+  PinnedRange(const void* p, size_t bytes) { id = PinRegistry::instance().acquire(p, bytes, &ilo, &ihi); }
   ~PinnedRange() { PinRegistry::instance().release(id); }
   PinnedRange(const PinnedRange&) = delete;
   PinnedRange& operator=(const PinnedRange&) = delete;
 };
+
+// A caller's linear host buffer [lo, hi) as the pipeline moves it: the pages page-locked inside it, and pinned library-owned
+// stand-ins for the fragments in front of and behind them (each shorter than a page).
+struct HostSpan {
+  uintptr_t lo = 0, hi = 0, ilo = 0, ihi = 0;                  // ilo == ihi == hi: nothing pinned, one pageable piece
+  char* head = nullptr;                                         // stands in for [lo, ilo)
+  char* tail = nullptr;                                         // ... and for [ihi, hi)
+  HostSpan(const void* p, size_t bytes, const PinnedRange& pin, char* frag_head, char* frag_tail) {
+    lo = reinterpret_cast<uintptr_t>(p);
+    hi = lo + bytes;
+    ilo = ihi = hi;
+    if (pin.id != 0 && pin.ilo - lo <= HostPipe::FRAG && hi - pin.ihi <= HostPipe::FRAG) {
+      ilo = pin.ilo;
+      ihi = pin.ihi;
+      head = frag_head;
+      tail = frag_tail;
+    }
+  }
+  bool pinned() const { return ilo != hi || ihi != hi; }
+  void stage_in() const {                                       // before the first host-to-device copy
+    if (!pinned()) return;
+    std::memcpy(head, reinterpret_cast<const void*>(lo), ilo - lo);
+    std::memcpy(tail, reinterpret_cast<const void*>(ihi), hi - ihi);
+  }
+  void stage_out() const {                                      // after the last device-to-host copy has completed
+    if (!pinned()) return;
+    std::memcpy(reinterpret_cast<void*>(lo), head, ilo - lo);
+    std::memcpy(reinterpret_cast<void*>(ihi), tail, hi - ihi);
+  }
+};
+
+// One linear host<->device copy of `bytes` at `host` inside `span`, cut at the edges of the pinned pages: a transfer never
+// straddles pinned and pageable memory (HIP decides by the first address how to move all of it), and the fragments move
+// through the pinned stand-ins.
+static hipError_t copy_split(char* dev, char* host, size_t bytes, bool to_device, hipStream_t s, const HostSpan& span) {
+  const uintptr_t h0 = reinterpret_cast<uintptr_t>(host), h1 = h0 + bytes;
+  if (!span.pinned())
+    return to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+  const uintptr_t c1 = std::min(std::max(span.ilo, h0), h1), c2 = std::max(c1, std::min(std::max(span.ihi, h0), h1));
+  const uintptr_t cuts[4] = {h0, c1, c2, h1};
+  for (int i = 0; i < 3; ++i) {
+    const size_t n = cuts[i + 1] - cuts[i];
+    if (n == 0) continue;
+    char* hp = i == 1 ? reinterpret_cast<char*>(cuts[i])                                   // the caller's pinned pages
+                      : (i == 0 ? span.head + (cuts[i] - span.lo) : span.tail + (cuts[i] - span.ihi));
+    char* dp = dev + (cuts[i] - h0);
+    const hipError_t e = to_device ? hipMemcpyAsync(dp, hp, n, hipMemcpyHostToDevice, s) : hipMemcpyAsync(hp, dp, n, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 static size_t host_block_columns(size_t rows, size_t M) {
   // 4..32 MiB per block (the link is at 90 % of its rate from 4 MiB on, 98 % at 32 MiB), at least ~8 blocks per call so
@@ -2044,9 +2111,15 @@ static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x
   rc = pp.reserve(std::max(ldd_x, ldd_y) * cb, x_base != nullptr ? M : 0);
   if (rc != SRI_OK) return rc;
 
-  PinnedRange pin_x(X, ((M - 1) * ldx + rows) * sizeof(double));
-  PinnedRange pin_y(Y, ((M - 1) * ldy + rows) * sizeof(double));
+  // (strided panels move by 2-D copies, which cannot be cut at page edges: those stay pageable)
+  PinnedRange pin_x(x_linear ? X : nullptr, M * rows * sizeof(double));
+  PinnedRange pin_y(y_linear ? Y : nullptr, M * rows * sizeof(double));
   PinnedRange pin_b(x_base, x_base != nullptr ? M * sizeof(double) : 0);
+  const HostSpan span_x(X, M * rows * sizeof(double), pin_x, pp.frag, pp.frag + HostPipe::FRAG);
+  const HostSpan span_b(x_base, x_base != nullptr ? M * sizeof(double) : 0, pin_b, pp.frag + 2 * HostPipe::FRAG, pp.frag + 3 * HostPipe::FRAG);
+  const HostSpan span_y(Y, M * rows * sizeof(double), pin_y, pp.frag + 4 * HostPipe::FRAG, pp.frag + 5 * HostPipe::FRAG);
+  span_x.stage_in();
+  span_b.stage_in();
 
   auto fail = [&](int code) { pp.drain(); return code; };
 #define PIPE_HIP(call)                                           \
@@ -2060,7 +2133,8 @@ static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x
     }                                                            \
   } while (0)
 
-  if (x_base != nullptr) PIPE_HIP(hipMemcpyAsync(pp.dB, x_base, M * sizeof(double), hipMemcpyHostToDevice, pp.s_in));
+  if (x_base != nullptr)
+    PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dB), reinterpret_cast<char*>(const_cast<double*>(x_base)), M * sizeof(double), true, pp.s_in, span_b));
   size_t b = 0;
   for (size_t c0 = 0; c0 < M; c0 += cb, ++b) {
     const int slot = static_cast<int>(b % HostPipe::SLOTS);
@@ -2069,7 +2143,8 @@ static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x
     // in: slot's X image is free once the apply that read it (block b - SLOTS) is done
     if (reuse) PIPE_HIP(hipStreamWaitEvent(pp.s_in, pp.applied[slot], 0));
     if (x_linear) {
-      PIPE_HIP(hipMemcpyAsync(pp.dX[slot], X + c0 * ldx, cols * rows * sizeof(double), hipMemcpyHostToDevice, pp.s_in));
+      PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dX[slot]), reinterpret_cast<char*>(const_cast<double*>(X + c0 * ldx)),
+                          cols * rows * sizeof(double), true, pp.s_in, span_x));
     } else {
       PIPE_HIP(hipMemcpy2DAsync(pp.dX[slot], ldd_x * sizeof(double), X + c0 * ldx, ldx * sizeof(double), rows * sizeof(double),
                                 cols, hipMemcpyHostToDevice, pp.s_in));
@@ -2084,7 +2159,8 @@ static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x
     // out
     PIPE_HIP(hipStreamWaitEvent(pp.s_out, pp.applied[slot], 0));
     if (y_linear) {
-      PIPE_HIP(hipMemcpyAsync(Y + c0 * ldy, pp.dY[slot], cols * rows * sizeof(double), hipMemcpyDeviceToHost, pp.s_out));
+      PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dY[slot]), reinterpret_cast<char*>(Y + c0 * ldy), cols * rows * sizeof(double), false,
+                          pp.s_out, span_y));
     } else {
       PIPE_HIP(hipMemcpy2DAsync(Y + c0 * ldy, ldy * sizeof(double), pp.dY[slot], ldd_y * sizeof(double), rows * sizeof(double),
                                 cols, hipMemcpyDeviceToHost, pp.s_out));
@@ -2095,6 +2171,7 @@ static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x
   PIPE_HIP(hipStreamSynchronize(pp.s_run));
   PIPE_HIP(hipStreamSynchronize(pp.s_in));
 #undef PIPE_HIP
+  span_y.stage_out();
   return SRI_OK;
 }
 

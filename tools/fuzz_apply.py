@@ -32,6 +32,11 @@ def main():
     lib = sri.load_library()
     bad = 0
     kernels = {}
+    # breadcrumbs on stderr, one short line per GPU phase, flushed BEFORE the call: a GPU fault aborts the process without a
+    # Python traceback, and tests/test_fuzz_gpu.py shows the tail of stderr — the last line then names the case and the call
+    def crumb(text):
+        print(text, file=sys.stderr, flush=True)
+
     for case in range(a.cases):
         kind = rng.choice(["cheb", "cheb", "dense"])
         if kind == "cheb":
@@ -76,6 +81,7 @@ def main():
         s = torch.cuda.current_stream().cuda_stream
         xp, yp = xbuf.data_ptr() + 8 * offx, ybuf.data_ptr() + 8 * offy
         use_tips = rng.random() < 0.5
+        crumb(f"case {case}: {kind} rows={rows} which={which} M={M} ldx={ldx} ldy={ldy} off=({offx},{offy}) tips={use_tips}: apply")
         if use_tips:
             rc = lib.sri_apply_tips(op._h, xp, ldx, yp, ldy, M, tips.data_ptr(), s)
         else:
@@ -95,6 +101,7 @@ def main():
         tip_ok = (not use_tips) or np.array_equal(tips.cpu().numpy(), want[0])
         host_ok = True
         if rng.random() < 0.25:
+            crumb(f"case {case}: apply_host X@{Xc.ctypes.data:#x} ({Xc.nbytes} bytes)")
             host = op.apply_host(Xc)
             host_ok = np.array_equal(host, want)
         integ_ok = True
@@ -105,6 +112,7 @@ def main():
             xb = rng.uniform(-1, 1, M)
             dxb = torch.from_numpy(xb).to(dev)
             ybuf.fill_(-7.25)
+            crumb(f"case {case}: integrate")
             rc = lib.sri_integrate(op._h, xp, ldx, dxb.data_ptr(), yp, ldy, M, s)
             torch.cuda.synchronize()
             Yi = ybuf.cpu().numpy()[offy:offy + M * ldy].reshape(M, ldy)
