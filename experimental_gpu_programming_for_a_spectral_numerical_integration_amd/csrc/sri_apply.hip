@@ -1487,7 +1487,7 @@ static int prepare_geometry(int dev) {
   if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
   if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
-  if constexpr (G::BM > 128) {                                  // ascending k order: only operators with rows > 512
+  if constexpr (G::BM >= 128) {                                 // ascending k order: only operators with rows > 512
     if (rc == SRI_OK) rc = prepare<G, true, false, false, EPI_NONE, 0, true>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true>(dev);
   }
@@ -1532,7 +1532,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
 template <class G>
 static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
-  if constexpr (G::BM > 128) {
+  if constexpr (G::BM >= 128) {
     if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
       if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;
       return args.tail_k != 0 ? launch<G, true, false, true, EPI_NONE, 0, true>(args, col_tiles, h->device, h->num_cus, h->max_workgroups, stream)
@@ -1623,12 +1623,17 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->num_cus = num_cus;
   h->rows = rows;
   h->which = which;
-  h->geo = rows <= 64 ? GEO_FLAT : (rows <= 128 ? GEO_MID : GEO_TALL);
+  // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry
+  // (0.77 of the MFMA peak at K = 128, 0.86 from K = 384 on: tile ends amortise over K) is the better choice whenever it
+  // saves a half-empty 256-row block, i.e. when the last 256-row block would hold at most 128 rows — measured N = 320:
+  // 0.54 -> 0.71, N = 384: 0.66 -> 0.86 of the peak (profiles/r03_sweep_n.jsonl).
+  const bool half_empty_last_block = rows > 256 && (rows - 1) % 256 < 128;
+  h->geo = rows <= 64 ? GEO_FLAT : ((rows <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
-  // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant only
-  // exists for the tall geometry — what is reported is always what pack_operator() and dispatch() use.
-  h->ascending = h->geo == GEO_TALL && rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
+  // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant exists for
+  // the two larger geometries — what is reported is always what pack_operator() and dispatch() use.
+  h->ascending = h->geo != GEO_FLAT && rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
   h->bm = h->geo == GEO_FLAT ? GeoFlat::BM : (h->geo == GEO_MID ? GeoMid::BM : GeoTall::BM);
   h->nk = (rows + BK - 1) / BK;
   h->row_blocks = (rows + h->bm - 1) / h->bm;
@@ -1643,7 +1648,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   try {
     const double* wf = (rows % BK != 0) ? w_host : nullptr;
     if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, wf, false, packed);
-    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, false, packed);
+    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
     else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
   } catch (const std::bad_alloc&) {
     delete h;
