@@ -79,12 +79,13 @@ def test_quaternion_rhs_kernel(sri):
 
 
 @pytest.mark.parametrize("n,rods", [(16, 5), (17, 40), (10, 3), (33, 70), (64, 333), (65, 100), (129, 50), (200, 77),
-                                    (256, 700), (257, 96), (513, 33)])
+                                    (256, 700), (257, 96), (513, 33), (300, 41), (385, 70), (641, 19)])
 def test_fused_quaternion_step(sri, oracle, n, rods):
     """sri_rod_quaternion_step (the right-hand side formed in the apply's store stage) against
     (a) the unfused composition integrate -> strain -> rhs of the same library: bit-identical, same operation order;
     (b) numpy on the oracle's Dn_NN^-1 / Dn_IN: 1e-12 relative Frobenius.  Covers all three geometries, the
-    register path (m < 16), tails (m % 16 != 0), whole multiples (m % 16 == 0) and ragged last column tiles."""
+    register path (m < 16), tails (m % 16 != 0), whole multiples (m % 16 == 0), ragged last column tiles and the 128-row
+    geometry with several row blocks (299, 384, 640 rows: it replaces a half-empty 256-row block)."""
     import torch
 
     m = n - 1
@@ -206,7 +207,7 @@ def test_nan_strain_is_reported_not_hidden(sri, n, resident):
         assert rod.iterations == 40                      # the streaming monitor carries the NaN through every iteration
 
 
-@pytest.mark.parametrize("n,rods", [(80, 37), (129, 16), (200, 5)])
+@pytest.mark.parametrize("n,rods", [(80, 37), (129, 16), (200, 5), (300, 6)])
 def test_large_grid_predictor_matches_oracle_and_plain_start(sri, oracle, n, rods):
     """N > 64: the fixed point started from the interpolated 32-node solution (default) and from Q = q_init must both
     land on the oracle's dense solve; the predictor only shortens the iteration."""
