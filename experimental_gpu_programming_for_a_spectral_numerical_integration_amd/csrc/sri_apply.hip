@@ -1384,10 +1384,10 @@ using GeoTall = Geo<4, 1, 4, 4, 2>;
 #elif SRI_TALL_WAVES == 16
 using GeoTall = Geo<4, 4, 4, 2, 3>;   // BM 256 x BN 128, 16 waves (64x32 each), 144 KiB ring, 1 WG/CU
 #else
-using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...)
+using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...) unless GeoMid pads less
 #endif
 // BM 128 x BN 128, 4 waves of 64 x 64 (the MFMA : fragment-read ratio of the tall geometry), TWO ring slots (one stage in
-// flight: 64 KiB) so that 2 WG share a CU and cover each other's waits: 64 < rows <= 128.  Measured at N = 128, 65 536 rods:
+// flight: 64 KiB) so that 2 WG share a CU and cover each other's waits: 64 < rows <= 128, and larger operators whose last 256-row block would be at most half full (create_from_matrix).  Measured at N = 128, 65 536 rods:
 // 0.138 ms against 0.146 ms for the previous 128 x 64 tile with three slots (+5.7 %).  (At N = 256, two row blocks, it is
 // 4 % behind the tall geometry: 0.531 vs 0.509 ms.)
 using GeoMid = Geo<2, 2, 4, 4, 2>;
