@@ -71,6 +71,30 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
     assert ("dma" in op.last_kernel) == expect_dma, op.last_kernel
 
 
+@pytest.mark.parametrize("n,which,M,geometry", [
+    (256, 0, 300, "256x128"),        # a full 256-row block
+    (257, 0, 300, "128x128"),        # 257 ... 384 rows: three 128-row blocks instead of two 256-row ones
+    (320, 0, 700, "128x128"),
+    (321, 1, 260, "128x128"),        # the integration operator of a 321-node grid: 320 rows, initial-value term as an epilogue
+    (384, 0, 129, "128x128"),
+    (385, 0, 200, "256x128"),        # the last 256-row block is more than half full again
+    (640, 0, 140, "128x128"),        # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
+    (641, 1, 90, "128x128"),         # 640 rows, paired order (integration operator)
+    (897, 0, 70, "256x128"),
+])
+def test_geometry_above_256_rows(sri, oracle, n, which, M, geometry):
+    """Rows are tiled in blocks of 128 or 256; above 256 rows the handle takes the 128-row geometry wherever the last
+    256-row block would be at most half full (round 3).  Same parity gate, same bit-exact model, whichever geometry runs."""
+    A = _operator_matrix(oracle, n, which)
+    rows = A.shape[0]
+    X = np.asfortranarray(rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M])
+    op = sri.SpectralApply(n, which)
+    Y = _run(op, X)
+    assert geometry in op.last_kernel, op.last_kernel
+    assert op.ascending_k == (rows > 512 and which != 1)
+    assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, op.last_kernel), ascending=op.ascending_k, kind="rod", which=which)
+
+
 def test_mfma_layout_exact_integers(sri):
     """Exact check of every index map (k order, row permutation, swizzle, tails) with small
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
