@@ -1969,8 +1969,9 @@ struct HostPipe {
 // inside a registered range shares it (reference counts: a read-only X used by several threads); one that partially overlaps a
 // registered range, or pages the caller (or anyone else) registered, or that cannot be locked, is not pinned at all — the copies
 // then take HIP's pageable path: slower, same stream program, same result.  What this design avoids on purpose: large
-// PAGEABLE transfers next to registered ranges — HIP pins such buffers on the fly and remembers the pins by address, and
-// two GPU memory faults on host-heap addresses in round 3's test runs point at that mixture.
+// PAGEABLE transfers next to registered ranges.  HIP page-locks large pageable buffers itself, on the fly; two runs of the
+// GPU test suite in round 3 died with a GPU memory fault on a host-heap address while the library mixed the two on the same
+// heap pages.  The mechanism was not isolated (the fault did not recur on demand); the mixture is what this form removes.
 class PinRegistry {
  public:
   static PinRegistry& instance() {
