@@ -54,6 +54,8 @@ C_ABI = {
     "sri_integrate_tips": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
     "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
+    "sri_apply_set_host_copy_threads": (_int, [_vp, _int]),
+    "sri_apply_set_host_memory_pinned": (_int, [_vp, _int]),
     "sri_apply_destroy": (_int, [_vp]),
     "sri_rod_create": (_int, [C.POINTER(_vp), _u32, _int]),
     "sri_rod_destroy": (_int, [_vp]),
@@ -374,6 +376,15 @@ class SpectralApply:
             raise ValueError("out must have as many columns as B")
         _chk(load_library().sri_integrate_host(self._h, _p(B), ldb, _p(xb), _p(Y), ldy, M), "sri_integrate_host")
         return Y
+
+    def set_host_copy_threads(self, threads: int) -> None:
+        """CPU threads that move host panels into / out of the handle's pinned staging slots (-1 = default, 0 = caller only)."""
+        _chk(load_library().sri_apply_set_host_copy_threads(self._h, int(threads)), "sri_apply_set_host_copy_threads")
+
+    def set_host_memory_pinned(self, pinned: bool) -> None:
+        """Promise that every host panel passed to this handle is page-locked (``hipHostMalloc`` / the caller's own
+        ``hipHostRegister``): copies then go straight from and to it.  A panel that is not is refused (``SRI_EINVAL``)."""
+        _chk(load_library().sri_apply_set_host_memory_pinned(self._h, 1 if pinned else 0), "sri_apply_set_host_memory_pinned")
 
     def set_max_workgroups(self, n: int) -> None:
         """Cap the persistent grid (0 = fill the chip): leaves CUs free for an overlapped collective."""

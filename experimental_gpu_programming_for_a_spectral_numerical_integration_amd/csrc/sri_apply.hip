@@ -1397,24 +1397,6 @@ enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2 };
 
 }  // namespace sri
 
-namespace sri { struct HostPipe; }
-
-struct sri_apply_handle {
-  int device = 0;
-  uint32_t rows = 0;
-  int which = -1;
-  int geo = 0;
-  uint32_t bm = 0, nk = 0, row_blocks = 0;
-  int num_cus = 0;
-  uint32_t max_workgroups = 0;   // 0 = fill the chip; else cap of the persistent grid (leave CUs to a collective)
-  double* d_apack = nullptr;
-  double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
-  double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
-  bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
-  std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
-  sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events and device slots, built on first use
-};
-
 namespace sri {
 
 // `w` (optional, rows % 16 != 0 only): the rank-1 factor, packed negated as operator column k = rows — the free slot of
@@ -1774,6 +1756,11 @@ int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const doub
   return run(h, dG, ldg, dG_next, ldn, M, d_x_base, static_cast<hipStream_t>(stream), d_tips, &quat, partials);
 }
 
+// what sri_host_panels.hip enqueues for a block that sits in one of its device slots (plain apply, or sri_integrate's form)
+int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_x_base, void* stream) {
+  return run(h, dX, ldx, dY, ldy, M, d_x_base, static_cast<hipStream_t>(stream));
+}
+
 uint32_t max_partials(const sri_apply_t* h) { return h ? static_cast<uint32_t>(h->num_cus) * 8u * 4u : 0; }
 
 uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 0; }
@@ -1874,326 +1861,6 @@ int sri_integrate(sri_apply_t* h, const double* dB, size_t ldb, const double* d_
   return sri::run(h, dB, ldb, dY, ldy, M, d_x_base, static_cast<hipStream_t>(hip_stream));
 }
 
-}  // extern "C"
-
-namespace sri {
-
-// ---------------------------------------------------------------------------------------------
-// Host panels (sri_apply_host / sri_integrate_host — what the drop-in header calls).
-// The panel crosses PCIe in blocks of columns through a ring of device slots; three streams carry block b+1 to the card,
-// apply block b and bring block b-1 back at the same time, so a call costs about ONE direction of the link (both
-// directions run at once: 48 GB/s each way measured, tools/host_transfer_probe.hip) instead of in + apply + out.
-// The caller's buffers are page-locked for the duration of the call (hipHostRegister; a range the caller registered
-// itself is left alone) so that the copies really are asynchronous; if that fails the same stream program runs on
-// pageable memory, where HIP makes each copy block the host — slower, same result.
-// ---------------------------------------------------------------------------------------------
-struct HostPipe {
-  static constexpr int SLOTS = 3;
-  hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
-  hipEvent_t landed[SLOTS] = {}, applied[SLOTS] = {}, returned[SLOTS] = {};
-  double* dX[SLOTS] = {};
-  double* dY[SLOTS] = {};
-  double* dB = nullptr;
-  size_t slot_doubles = 0, base_doubles = 0;
-  // pinned, library-owned: the head and tail fragments (< one page each) of X, x_base and Y that lie outside the pages
-  // page-locked in the caller's buffers (PinRegistry) pass through here, so that no pageable transfer sits in the pipeline
-  static constexpr size_t FRAG = 4096;
-  char* frag = nullptr;                                         // 6 x FRAG: X head, X tail, x_base head, x_base tail, Y head, Y tail
-
-  int reserve(size_t doubles_per_slot, size_t base) {
-    if (frag == nullptr && hipHostMalloc(reinterpret_cast<void**>(&frag), 6 * FRAG, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      frag = nullptr;
-      return SRI_ENOMEM;
-    }
-    if (s_in == nullptr) {
-      SRI_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
-      SRI_HIP(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking));
-      SRI_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
-      for (int i = 0; i < SLOTS; ++i) {
-        SRI_HIP(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
-        SRI_HIP(hipEventCreateWithFlags(&applied[i], hipEventDisableTiming));
-        SRI_HIP(hipEventCreateWithFlags(&returned[i], hipEventDisableTiming));
-      }
-    }
-    if (doubles_per_slot > slot_doubles) {
-      for (int i = 0; i < SLOTS; ++i) {
-        if (dX[i]) (void)hipFree(dX[i]);
-        if (dY[i]) (void)hipFree(dY[i]);
-        dX[i] = dY[i] = nullptr;
-      }
-      slot_doubles = 0;
-      for (int i = 0; i < SLOTS; ++i) {
-        if (hipMalloc(&dX[i], doubles_per_slot * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
-        if (hipMalloc(&dY[i], doubles_per_slot * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
-      }
-      slot_doubles = doubles_per_slot;
-    }
-    if (base > base_doubles) {
-      if (dB) (void)hipFree(dB);
-      dB = nullptr;
-      base_doubles = 0;
-      if (hipMalloc(&dB, base * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return SRI_ENOMEM; }
-      base_doubles = base;
-    }
-    return SRI_OK;
-  }
-  void drain() {
-    if (s_in) (void)hipStreamSynchronize(s_in);
-    if (s_run) (void)hipStreamSynchronize(s_run);
-    if (s_out) (void)hipStreamSynchronize(s_out);
-  }
-  ~HostPipe() {
-    drain();
-    for (int i = 0; i < SLOTS; ++i) {
-      if (dX[i]) (void)hipFree(dX[i]);
-      if (dY[i]) (void)hipFree(dY[i]);
-      if (landed[i]) (void)hipEventDestroy(landed[i]);
-      if (applied[i]) (void)hipEventDestroy(applied[i]);
-      if (returned[i]) (void)hipEventDestroy(returned[i]);
-    }
-    if (dB) (void)hipFree(dB);
-    if (frag) (void)hipHostFree(frag);
-    if (s_in) (void)hipStreamDestroy(s_in);
-    if (s_run) (void)hipStreamDestroy(s_run);
-    if (s_out) (void)hipStreamDestroy(s_out);
-  }
-};
-
-// Page-locks the caller's host panel for the lifetime of the object — through a process-wide registry, and only the pages that
-// lie WHOLLY inside [ptr, ptr + bytes).  Registrations are page-granular and do not nest; two handles (one host thread per GPU
-// is the documented sharding) working on adjacent column slabs of ONE host buffer, or X and Y of one call that the allocator
-// placed back to back, share a boundary page.  With interior pages only, the registered ranges of distinct buffers never touch,
-// so every panel of a megabyte or more is pinned, whatever its neighbours are; the head and tail fragments (< 4 KiB each) go
-// as separate small copies, which HIP stages through its own buffers (copy_split in run_host).  A request whose interior lies
-// inside a registered range shares it (reference counts: a read-only X used by several threads); one that partially overlaps a
-// registered range, or pages the caller (or anyone else) registered, or that cannot be locked, is not pinned at all — the copies
-// then take HIP's pageable path: slower, same stream program, same result.  What this design avoids on purpose: large
-// PAGEABLE transfers next to registered ranges.  HIP page-locks large pageable buffers itself, on the fly; two runs of the
-// GPU test suite in round 3 died with a GPU memory fault on a host-heap address while the library mixed the two on the same
-// heap pages.  The mechanism was not isolated (the fault did not recur on demand); the mixture is what this form removes.
-class PinRegistry {
- public:
-  static PinRegistry& instance() {
-    static PinRegistry r;
-    return r;
-  }
-  // returns an id > 0 to pass to release() and the registered byte range [*ilo, *ihi), or 0 if nothing was pinned
-  size_t acquire(const void* p, size_t bytes, uintptr_t* ilo_out, uintptr_t* ihi_out) {
-    *ilo_out = *ihi_out = 0;
-    if (p == nullptr || bytes < kMinBytes) return 0;
-    const uintptr_t page = 4096;
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
-    const uintptr_t ilo = (lo + page - 1) & ~(page - 1), ihi = hi & ~(page - 1);          // the pages wholly inside
-    if (ihi <= ilo || ihi - ilo < kMinBytes / 2) return 0;
-    std::lock_guard<std::mutex> lock(mutex_);
-    for (Entry& e : entries_) {
-      if (ilo >= e.lo && ihi <= e.hi) { ++e.refs; *ilo_out = ilo; *ihi_out = ihi; return e.id; }   // inside a range we hold: share it
-      if (ilo < e.hi && e.lo < ihi) return 0;                           // genuinely overlapping buffers: leave it to HIP
-    }
-    if (hipHostRegister(reinterpret_cast<void*>(ilo), ihi - ilo, hipHostRegisterDefault) != hipSuccess) {
-      (void)hipGetLastError();                                          // the caller's own registration, or not lockable
-      return 0;
-    }
-    try {
-      entries_.push_back(Entry{ilo, ihi, 1, ++next_id_});
-    } catch (const std::bad_alloc&) {
-      (void)hipHostUnregister(reinterpret_cast<void*>(ilo));
-      return 0;
-    }
-    *ilo_out = ilo;
-    *ihi_out = ihi;
-    return next_id_;
-  }
-  void release(size_t id) {
-    if (id == 0) return;
-    std::lock_guard<std::mutex> lock(mutex_);
-    for (size_t i = 0; i < entries_.size(); ++i) {
-      if (entries_[i].id != id) continue;
-      if (--entries_[i].refs == 0) {
-        if (hipHostUnregister(reinterpret_cast<void*>(entries_[i].lo)) != hipSuccess) (void)hipGetLastError();   // never leave an error for the next launch check
-        entries_.erase(entries_.begin() + static_cast<std::ptrdiff_t>(i));
-      }
-      return;
-    }
-  }
-  static constexpr size_t kMinBytes = size_t(1) << 20;
-
- private:
-  struct Entry { uintptr_t lo, hi; int refs; size_t id; };    // registered (page-aligned) byte range
-  std::mutex mutex_;
-  std::vector<Entry> entries_;
-  size_t next_id_ = 0;
-};
-
-struct PinnedRange {
-  size_t id = 0;
-  uintptr_t ilo = 0, ihi = 0;                                   // the pinned part of the buffer (empty if id == 0)
-  PinnedRange(const void* p, size_t bytes) { id = PinRegistry::instance().acquire(p, bytes, &ilo, &ihi); }
-  ~PinnedRange() { PinRegistry::instance().release(id); }
-  PinnedRange(const PinnedRange&) = delete;
-  PinnedRange& operator=(const PinnedRange&) = delete;
-};
-
-// A caller's linear host buffer [lo, hi) as the pipeline moves it: the pages page-locked inside it, and pinned library-owned
-// stand-ins for the fragments in front of and behind them (each shorter than a page).
-struct HostSpan {
-  uintptr_t lo = 0, hi = 0, ilo = 0, ihi = 0;                  // ilo == ihi == hi: nothing pinned, one pageable piece
-  char* head = nullptr;                                         // stands in for [lo, ilo)
-  char* tail = nullptr;                                         // ... and for [ihi, hi)
-  HostSpan(const void* p, size_t bytes, const PinnedRange& pin, char* frag_head, char* frag_tail) {
-    lo = reinterpret_cast<uintptr_t>(p);
-    hi = lo + bytes;
-    ilo = ihi = hi;
-    if (pin.id != 0 && pin.ilo - lo <= HostPipe::FRAG && hi - pin.ihi <= HostPipe::FRAG) {
-      ilo = pin.ilo;
-      ihi = pin.ihi;
-      head = frag_head;
-      tail = frag_tail;
-    }
-  }
-  bool pinned() const { return ilo != hi || ihi != hi; }
-  void stage_in() const {                                       // before the first host-to-device copy
-    if (!pinned()) return;
-    std::memcpy(head, reinterpret_cast<const void*>(lo), ilo - lo);
-    std::memcpy(tail, reinterpret_cast<const void*>(ihi), hi - ihi);
-  }
-  void stage_out() const {                                      // after the last device-to-host copy has completed
-    if (!pinned()) return;
-    std::memcpy(reinterpret_cast<void*>(lo), head, ilo - lo);
-    std::memcpy(reinterpret_cast<void*>(ihi), tail, hi - ihi);
-  }
-};
-
-// One linear host<->device copy of `bytes` at `host` inside `span`, cut at the edges of the pinned pages: a transfer never
-// straddles pinned and pageable memory (HIP decides by the first address how to move all of it), and the fragments move
-// through the pinned stand-ins.
-static hipError_t copy_split(char* dev, char* host, size_t bytes, bool to_device, hipStream_t s, const HostSpan& span) {
-  const uintptr_t h0 = reinterpret_cast<uintptr_t>(host), h1 = h0 + bytes;
-  if (!span.pinned())
-    return to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
-  const uintptr_t c1 = std::min(std::max(span.ilo, h0), h1), c2 = std::max(c1, std::min(std::max(span.ihi, h0), h1));
-  const uintptr_t cuts[4] = {h0, c1, c2, h1};
-  for (int i = 0; i < 3; ++i) {
-    const size_t n = cuts[i + 1] - cuts[i];
-    if (n == 0) continue;
-    char* hp = i == 1 ? reinterpret_cast<char*>(cuts[i])                                   // the caller's pinned pages
-                      : (i == 0 ? span.head + (cuts[i] - span.lo) : span.tail + (cuts[i] - span.ihi));
-    char* dp = dev + (cuts[i] - h0);
-    const hipError_t e = to_device ? hipMemcpyAsync(dp, hp, n, hipMemcpyHostToDevice, s) : hipMemcpyAsync(hp, dp, n, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
-static size_t host_block_columns(size_t rows, size_t M) {
-  // 4..32 MiB per block (the link is at 90 % of its rate from 4 MiB on, 98 % at 32 MiB), at least ~8 blocks per call so
-  // that the three streams overlap, whole 128-column tiles.
-  const size_t col_bytes = rows * sizeof(double);
-  const size_t total = col_bytes * M;
-  size_t target = total / 8;
-  target = std::min<size_t>(std::max<size_t>(target, size_t(4) << 20), size_t(32) << 20);
-  size_t cols = std::max<size_t>(target / col_bytes, 1);
-  cols = (cols + 127) & ~size_t(127);
-  return std::min(cols, (M + 127) & ~size_t(127));
-}
-
-static int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x_base, double* Y, size_t ldy, size_t M) {
-  if (h == nullptr || (M > 0 && (X == nullptr || Y == nullptr)) || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
-  if (M == 0) return SRI_OK;
-  DeviceGuard guard;
-  int rc = guard.enter(h->device);
-  if (rc != SRI_OK) return rc;
-  const size_t rows = h->rows;
-  // Device image of a block.  A contiguous host panel is copied as it lies (one linear copy per block; the kernel takes
-  // any leading dimension); a strided one is compacted by a 2-D copy to an even leading dimension.
-  const bool x_linear = ldx == rows, y_linear = ldy == rows;
-  const size_t ldd_x = x_linear ? rows : ((rows + 1) & ~size_t(1));
-  const size_t ldd_y = y_linear ? rows : ((rows + 1) & ~size_t(1));
-  const size_t cb = host_block_columns(rows, M);
-  if (h->pipe == nullptr) h->pipe = new (std::nothrow) HostPipe();
-  if (h->pipe == nullptr) return SRI_ENOMEM;
-  HostPipe& pp = *h->pipe;
-  rc = pp.reserve(std::max(ldd_x, ldd_y) * cb, x_base != nullptr ? M : 0);
-  if (rc != SRI_OK) return rc;
-
-  // (strided panels move by 2-D copies, which cannot be cut at page edges: those stay pageable)
-  PinnedRange pin_x(x_linear ? X : nullptr, M * rows * sizeof(double));
-  PinnedRange pin_y(y_linear ? Y : nullptr, M * rows * sizeof(double));
-  PinnedRange pin_b(x_base, x_base != nullptr ? M * sizeof(double) : 0);
-  const HostSpan span_x(X, M * rows * sizeof(double), pin_x, pp.frag, pp.frag + HostPipe::FRAG);
-  const HostSpan span_b(x_base, x_base != nullptr ? M * sizeof(double) : 0, pin_b, pp.frag + 2 * HostPipe::FRAG, pp.frag + 3 * HostPipe::FRAG);
-  const HostSpan span_y(Y, M * rows * sizeof(double), pin_y, pp.frag + 4 * HostPipe::FRAG, pp.frag + 5 * HostPipe::FRAG);
-  span_x.stage_in();
-  span_b.stage_in();
-
-  auto fail = [&](int code) { pp.drain(); return code; };
-#define PIPE_HIP(call)                                           \
-  do {                                                           \
-    hipError_t e__ = (call);                                     \
-    if (e__ != hipSuccess) {                                     \
-      g_last_hip_error = static_cast<int>(e__);                  \
-      (void)hipGetLastError();                                   \
-      if (std::getenv("SRI_DEBUG")) std::fprintf(stderr, "sri host pipe: %s -> %s\n", #call, hipGetErrorString(e__)); \
-      return fail(SRI_EHIP);                                     \
-    }                                                            \
-  } while (0)
-
-  if (x_base != nullptr)
-    PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dB), reinterpret_cast<char*>(const_cast<double*>(x_base)), M * sizeof(double), true, pp.s_in, span_b));
-  size_t b = 0;
-  for (size_t c0 = 0; c0 < M; c0 += cb, ++b) {
-    const int slot = static_cast<int>(b % HostPipe::SLOTS);
-    const size_t cols = std::min(cb, M - c0);
-    const bool reuse = b >= static_cast<size_t>(HostPipe::SLOTS);
-    // in: slot's X image is free once the apply that read it (block b - SLOTS) is done
-    if (reuse) PIPE_HIP(hipStreamWaitEvent(pp.s_in, pp.applied[slot], 0));
-    if (x_linear) {
-      PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dX[slot]), reinterpret_cast<char*>(const_cast<double*>(X + c0 * ldx)),
-                          cols * rows * sizeof(double), true, pp.s_in, span_x));
-    } else {
-      PIPE_HIP(hipMemcpy2DAsync(pp.dX[slot], ldd_x * sizeof(double), X + c0 * ldx, ldx * sizeof(double), rows * sizeof(double),
-                                cols, hipMemcpyHostToDevice, pp.s_in));
-    }
-    PIPE_HIP(hipEventRecord(pp.landed[slot], pp.s_in));
-    // run: needs the block, and the slot's Y image back on the host (block b - SLOTS)
-    PIPE_HIP(hipStreamWaitEvent(pp.s_run, pp.landed[slot], 0));
-    if (reuse) PIPE_HIP(hipStreamWaitEvent(pp.s_run, pp.returned[slot], 0));
-    rc = run(h, pp.dX[slot], ldd_x, pp.dY[slot], ldd_y, cols, x_base != nullptr ? pp.dB + c0 : nullptr, pp.s_run);
-    if (rc != SRI_OK) return fail(rc);
-    PIPE_HIP(hipEventRecord(pp.applied[slot], pp.s_run));
-    // out
-    PIPE_HIP(hipStreamWaitEvent(pp.s_out, pp.applied[slot], 0));
-    if (y_linear) {
-      PIPE_HIP(copy_split(reinterpret_cast<char*>(pp.dY[slot]), reinterpret_cast<char*>(Y + c0 * ldy), cols * rows * sizeof(double), false,
-                          pp.s_out, span_y));
-    } else {
-      PIPE_HIP(hipMemcpy2DAsync(Y + c0 * ldy, ldy * sizeof(double), pp.dY[slot], ldd_y * sizeof(double), rows * sizeof(double),
-                                cols, hipMemcpyDeviceToHost, pp.s_out));
-    }
-    PIPE_HIP(hipEventRecord(pp.returned[slot], pp.s_out));
-  }
-  PIPE_HIP(hipStreamSynchronize(pp.s_out));                  // the last thing in every chain
-  PIPE_HIP(hipStreamSynchronize(pp.s_run));
-  PIPE_HIP(hipStreamSynchronize(pp.s_in));
-#undef PIPE_HIP
-  span_y.stage_out();
-  return SRI_OK;
-}
-
-}  // namespace sri
-
-extern "C" {
-
-int sri_apply_host(sri_apply_t* h, const double* X, size_t ldx, double* Y, size_t ldy, size_t M) {
-  return sri::run_host(h, X, ldx, nullptr, Y, ldy, M);
-}
-
-int sri_integrate_host(sri_apply_t* h, const double* B, size_t ldb, const double* x_base, double* Y, size_t ldy, size_t M) {
-  if (h == nullptr || h->which != SRI_OP_DNN_INV || x_base == nullptr) return SRI_EINVAL;
-  return sri::run_host(h, B, ldb, x_base, Y, ldy, M);
-}
-
 int sri_apply_destroy(sri_apply_t* h) {
   if (h == nullptr) return SRI_OK;
   sri::DeviceGuard guard;
@@ -2201,7 +1868,7 @@ int sri_apply_destroy(sri_apply_t* h) {
   if (h->d_apack) (void)hipFree(h->d_apack);
   if (h->d_apack_small) (void)hipFree(h->d_apack_small);
   if (h->d_w) (void)hipFree(h->d_w);
-  delete h->pipe;
+  sri::host_pipe_destroy(h->pipe);   // sri_host_panels.hip
   delete h;
   return SRI_OK;
 }

@@ -103,10 +103,37 @@ inline constexpr int row_of_slot(int tm, int j) { return 32 * (tm >> 1) + 2 * j 
 inline constexpr int k_of_ascending(int j, int g, int e) { return 8 * j + 4 * e + g; }
 inline constexpr int k_of_paired(int j, int g, int e) { return 8 * j + 2 * g + e; }
 
+// ---- host panels (sri_host_panels.hip): the pinned staging ring + copy threads behind sri_apply_host / sri_integrate_host ----
+struct HostPipe;
+void host_pipe_destroy(HostPipe* pipe);              // the handle's device must be current
+// the apply on a block that already sits on the device (sri_apply.hip); d_x_base != nullptr: sri_integrate's form
+int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_x_base, void* stream);
+
 #if defined(SRI_DEVICE_HELPERS)   /* defined by the .hip translation units after <hip/hip_runtime.h> */
 }  // namespace sri
+#include <atomic>
 #include <tuple>
 #include <utility>
+
+// The apply handle (sri_apply.hip creates, launches and destroys it; sri_host_panels.hip hangs its pipe on it).
+struct sri_apply_handle {
+  int device = 0;
+  uint32_t rows = 0;
+  int which = -1;
+  int geo = 0;
+  uint32_t bm = 0, nk = 0, row_blocks = 0;
+  int num_cus = 0;
+  uint32_t max_workgroups = 0;   // 0 = fill the chip; else cap of the persistent grid (leave CUs to a collective)
+  double* d_apack = nullptr;
+  double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
+  double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
+  bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
+  std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
+  sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use
+  int host_copy_threads = -1;      // CPU threads that move a host panel into / out of the pinned staging slots; -1 = default
+  bool host_memory_pinned = false; // the caller promised page-locked X / Y / x_base: no staging (sri_apply_set_host_memory_pinned)
+};
+
 namespace sri {
 // Enqueue `kernel` and return the launch's OWN status.  (hipLaunchKernelGGL + hipGetLastError reports whatever failed
 // last on this thread — also a call of the application's, or a refused hipHostRegister — as a failed launch.)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRI_ABI_VERSION 3
+#define SRI_ABI_VERSION 4
 
 typedef enum sri_status {
     SRI_OK = 0,
@@ -153,16 +153,28 @@ int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_
 int sri_integrate_tips(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
                        double *dY, size_t ldy, size_t M, double *d_tips, void *hip_stream);
 
-/* For callers holding HOST panels (what include/chebyshev_differentiation.h calls): the panel crosses PCIe in
- * blocks of columns on three streams — block b+1 on its way in, block b applied, block b-1 on its way back — so a
- * call costs about one direction of the link, not in + apply + out.  X and Y are page-locked for the duration of the
- * call (ranges the caller registered itself are left alone; if locking fails the copies take HIP's pageable path).
- * Y may be X (in place).  Returns when Y is complete.  (PCIe-inclusive; never what bench.py times.) */
+/* For callers holding HOST panels (what include/chebyshev_differentiation.h calls for the reference's main.cpp:166-172):
+ * the panel crosses PCIe in blocks of columns — CPU threads copy block b+1 into a pinned staging slot owned by the handle
+ * while the copy engines carry block b in, the kernel applies block b-1 and earlier blocks travel back and are copied
+ * out — so a call costs about one direction of the link, not in + apply + out.  The library never page-locks, registers
+ * or hands to the GPU runtime any of the caller's memory: X, Y and x_base are only read and written by the CPU.
+ * X and Y: column-major rows x M, any leading dimension >= rows; Y may be X (in place), otherwise they must not overlap.
+ * Returns when Y is complete.  (PCIe-inclusive; never what bench.py times.) */
 int sri_apply_host(sri_apply_t *h, const double *X, size_t ldx, double *Y, size_t ldy, size_t M);
 
 /* Host-buffer form of sri_integrate (x_base: M host doubles). */
 int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double *x_base,
                        double *Y, size_t ldy, size_t M);
+
+/* CPU threads that copy a host panel into / out of the staging slots (besides the calling thread, which helps):
+ * -1 = default (SRI_HOST_COPY_THREADS in the environment, else min(8, hardware threads)), 0 = the calling thread alone. */
+int sri_apply_set_host_copy_threads(sri_apply_t *h, int threads);
+
+/* pinned != 0: the caller PROMISES that every X, Y and x_base it passes to the _host entry points of this handle is
+ * page-locked host memory (hipHostMalloc, or the caller's own hipHostRegister held across the call).  The copies then go
+ * straight from and to the caller's memory — no staging, no CPU copy; the claim is checked (hipPointerGetAttributes on the
+ * ends of each range) and a call whose buffers are not page-locked returns SRI_EINVAL.  Default 0. */
+int sri_apply_set_host_memory_pinned(sri_apply_t *h, int pinned);
 
 int sri_apply_destroy(sri_apply_t *h);
 

@@ -9,28 +9,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _keep_freed_host_memory_mapped():
-    """Test-process hygiene on the GPU box, not a product requirement.  The tests move many large, short-lived numpy / torch
-    CPU buffers to and from the GPU; HIP page-locks such pageable buffers on the fly, and glibc returns freed ones to the
-    kernel (heap trimming, munmap) and hands the same addresses out again a moment later.  Two runs of this suite in round 3
-    ended in `Memory access fault by GPU ... on address <host heap page>`; whatever the exact mechanism, it needs host
-    memory that was unmapped under a page-lock.  With trimming off and the mmap threshold at its maximum, freed buffers of
-    up to 32 MiB stay mapped for the life of the process (and of the tests' subprocesses, through the environment)."""
-    os.environ.setdefault("MALLOC_TRIM_THRESHOLD_", str(2**31 - 1))
-    os.environ.setdefault("MALLOC_MMAP_THRESHOLD_", str(32 << 20))
-    try:
-        import ctypes
-
-        libc = ctypes.CDLL("libc.so.6")
-        libc.mallopt(-1, 2**31 - 1)          # M_TRIM_THRESHOLD
-        libc.mallopt(-3, 32 << 20)           # M_MMAP_THRESHOLD (its maximum)
-    except OSError:
-        pass
-
-
-_keep_freed_host_memory_mapped()
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

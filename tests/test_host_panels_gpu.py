@@ -1,7 +1,12 @@
 """Host panels through the C ABI (sri_apply_host / sri_integrate_host — what the drop-in header calls).
 
-The panel crosses PCIe in blocks on three streams (in / apply / out); the result must be the device path's, bit for bit,
-whatever the blocking: several blocks, ragged last block, strided panels, odd row counts, in place, growing sizes.
+The panel crosses PCIe in blocks: CPU threads copy it into and out of pinned staging slots owned by the handle, three streams
+carry the blocks in / apply them / bring them back (csrc/sri_host_panels.hip; the stage order itself is checked on the CPU
+against a mock card, tests/test_host_pipeline.py).  The result must be the device path's, bit for bit, whatever the blocking:
+several blocks, ragged last block, strided panels, odd row counts, in place, growing sizes — with ordinary pageable numpy
+memory on the caller's side and ordinary pageable torch transfers next to it in the same process, under the process's
+default allocator settings (round 3 ran this file with malloc trimming disabled; nothing here depends on that any more:
+the library no longer page-locks, registers or hands to HIP any caller memory).
 """
 import numpy as np
 import pytest
@@ -94,7 +99,7 @@ def test_host_panel_argument_errors(sri):
 
 
 def test_read_only_host_panel(sri):
-    """A panel that cannot be page-locked for writing (read-only mapping) still goes through (pageable copies)."""
+    """A read-only input (numpy write flag off) is only ever read — by the CPU — on its way into the staging slots."""
     n, M = 64, 20_000
     op = sri.SpectralApply(n, 0)
     X = uniform_panel(n, M)
@@ -138,8 +143,8 @@ def test_a_failed_hip_call_of_the_caller_is_not_reported_as_a_failed_launch(sri)
 def test_two_threads_on_adjacent_slabs_and_a_shared_input(sri):
     """The documented sharding — one host thread and one handle per slab — on ONE host allocation: the slabs are adjacent
     (they share a boundary page: 255-row columns are 2 040 bytes), and a second pair of threads reads the SAME input.
-    Page-locking is page-granular and does not nest, so the library keeps a reference-counted registry of what it pinned;
-    a call that finishes early must not unlock pages another call still copies from.  Repeated, against the device path."""
+    Each handle owns its staging ring and copy threads; the caller's memory is shared between the calls but only touched by
+    CPU copies, so a call that finishes early has nothing to release under another one.  Repeated, against the device path."""
     import threading
 
     n, which, M = 256, 1, 12_001                                   # 255 rows: nothing is page aligned
@@ -172,3 +177,62 @@ def test_two_threads_on_adjacent_slabs_and_a_shared_input(sri):
     assert not errors, errors
     assert np.array_equal(Y, ref)
     assert np.array_equal(Z[0], ref[:, :M]) and np.array_equal(Z[1], ref[:, :M])
+
+
+def test_pageable_transfers_of_the_caller_next_to_host_panel_calls(sri):
+    """What a C++ host does next to sri_apply_host (and what round 3's page-locking could not live with): its own large
+    pageable copies from and to freshly allocated, freed and recycled heap buffers — the SAME buffers the library is
+    handed, and neighbours that share their first and last pages — interleaved with host-panel calls.  Default allocator."""
+    import torch
+
+    n, which, M = 256, 1, 16_385                                    # 255 rows: 2 040-byte columns, nothing page aligned
+    op = sri.SpectralApply(n, which)
+    rows = op.rows
+    ref_op = sri.SpectralApply(n, which)
+    for rep in range(6):
+        big = uniform_panel(rows, 3 * M, seed=100 + rep)           # fresh heap memory every round (freed at the end of it)
+        X = big[:, M:2 * M]                                         # the middle slab: both neighbours share its boundary pages
+        left = torch.from_numpy(np.ascontiguousarray(big[:, :M].T)).cuda()          # pageable copy of the left neighbour
+        Y = np.asfortranarray(np.full((rows, M), np.nan))
+        op.apply_host(X, out=Y)
+        same = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()                   # pageable copy of the very buffer just used
+        right = torch.from_numpy(np.ascontiguousarray(big[:, 2 * M:].T)).cuda()
+        back = ref_op.apply(same).cpu().numpy()                                     # pageable copy back into fresh memory
+        assert np.array_equal(Y, np.asfortranarray(back.T)), rep
+        assert np.array_equal(left.cpu().numpy().T, big[:, :M]) and np.array_equal(right.cpu().numpy().T, big[:, 2 * M:])
+        del big, X, Y, left, same, right, back
+
+
+def test_copy_thread_settings_give_the_same_bits(sri):
+    n, M = 256, 30_001
+    op = sri.SpectralApply(n, 0)
+    X = uniform_panel(n, M, seed=5)
+    want = _device_apply(op, X)
+    for threads in (0, 1, 3, -1):
+        op.set_host_copy_threads(threads)
+        assert np.array_equal(op.apply_host(X), want), threads
+    with pytest.raises(RuntimeError):
+        op.set_host_copy_threads(1000)
+
+
+def test_caller_pinned_memory_is_used_in_place_and_the_claim_is_checked(sri):
+    """sri_apply_set_host_memory_pinned: a caller whose panels are page-locked (torch's pinned allocator here, hipHostMalloc
+    in C++) skips the staging copies; a panel that is NOT page-locked is refused instead of being handed to the copy engines."""
+    import torch
+
+    n, M = 256, 40_000
+    op = sri.SpectralApply(n, sri.OP_DNN_INV)
+    rows = op.rows
+    X = uniform_panel(rows, M, seed=9)
+    xb = np.random.default_rng(10).uniform(-1, 1, M)
+    want = _device_integrate(op, X, xb)
+    Xp = torch.from_numpy(np.ascontiguousarray(X.T)).pin_memory()
+    Yp = torch.empty_like(Xp).pin_memory()
+    bp = torch.from_numpy(xb).pin_memory()
+    op.set_host_memory_pinned(True)
+    out = op.integrate_host(Xp.numpy().T, bp.numpy(), out=Yp.numpy().T)
+    assert np.array_equal(out, want)
+    with pytest.raises(RuntimeError):
+        op.integrate_host(X, xb)                                    # plain numpy memory: the promise does not hold
+    op.set_host_memory_pinned(False)
+    assert np.array_equal(op.integrate_host(X, xb), want)           # back on the staged path
