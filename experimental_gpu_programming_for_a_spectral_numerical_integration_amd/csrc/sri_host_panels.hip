@@ -49,14 +49,15 @@ struct PanelDeviceGuard {
 };
 
 unsigned default_copy_threads() {
-  // 8 threads move ~ 2 x 50 GB/s between pageable and pinned memory on the GPU box's host (profiles/r04_host_panel_bench.jsonl
-  // has the sweep); never more than the machine has, and the calling thread works too.
+  // Four threads plus the calling one keep both directions of the link fed on the GPU box's host (12.8 ms per 0.54 GB panel
+  // against 12.0 ms straight from page-locked memory; 2 threads: 17.2, none: 40.9; more than 4 buy nothing —
+  // profiles/r04_host_panel_bench.jsonl), and a node runs one handle per GPU.
   if (const char* v = std::getenv("SRI_HOST_COPY_THREADS")) {
     const long n = std::strtol(v, nullptr, 10);
     if (n >= 0 && n <= 64) return static_cast<unsigned>(n);
   }
   const unsigned hw = std::thread::hardware_concurrency();
-  return hw == 0 ? 4u : std::min(8u, hw);
+  return hw == 0 ? 4u : std::min(4u, hw);
 }
 
 }  // namespace
@@ -272,7 +273,11 @@ int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x_base, 
     return SRI_EHIP;
   }
   const size_t rows = h->rows;
-  const size_t cb = host_block_columns(rows, M);
+  size_t cb = host_block_columns(rows, M);
+  if (const char* v = std::getenv("SRI_HOST_BLOCK_COLS")) {      // diagnostics (tools/host_panel_bench.py --block-cols): whole tiles
+    const long n = std::strtol(v, nullptr, 10);
+    if (n >= 128 && n <= (1L << 24)) cb = static_cast<size_t>(n) & ~size_t(127);
+  }
   if (h->pipe == nullptr) {
     const unsigned threads = h->host_copy_threads >= 0 ? static_cast<unsigned>(h->host_copy_threads) : default_copy_threads();
     h->pipe = new (std::nothrow) HostPipe(threads);

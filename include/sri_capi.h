@@ -167,7 +167,7 @@ int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double
                        double *Y, size_t ldy, size_t M);
 
 /* CPU threads that copy a host panel into / out of the staging slots (besides the calling thread, which helps):
- * -1 = default (SRI_HOST_COPY_THREADS in the environment, else min(8, hardware threads)), 0 = the calling thread alone. */
+ * -1 = default (SRI_HOST_COPY_THREADS in the environment, else min(4, hardware threads)), 0 = the calling thread alone. */
 int sri_apply_set_host_copy_threads(sri_apply_t *h, int threads);
 
 /* pinned != 0: the caller PROMISES that every X, Y and x_base it passes to the _host entry points of this handle is

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--threads", type=str, default="-1")
     ap.add_argument("--pinned", action="store_true")
+    ap.add_argument("--block-cols", type=str, default="", help="comma list: override the library's block size (diagnostics)")
     args = ap.parse_args()
     import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
 
@@ -50,9 +51,13 @@ def main():
     X = np.asfortranarray(rng.uniform(-1, 1, size=(M, rows)).T)
     Y = np.empty((rows, M), order="F")
     for threads in [int(t) for t in args.threads.split(",")]:
-        op = sri.SpectralApply(args.n, args.which)
-        op.set_host_copy_threads(threads)
-        measure(op, X, Y, "staged (pageable caller memory)", {"copy_threads": threads})
+        for bc in (args.block_cols.split(",") if args.block_cols else [""]):
+            if bc:
+                os.environ["SRI_HOST_BLOCK_COLS"] = bc
+            op = sri.SpectralApply(args.n, args.which)
+            op.set_host_copy_threads(threads)
+            measure(op, X, Y, "staged (pageable caller memory)", {"copy_threads": threads, "block_cols": bc or "library"})
+    os.environ.pop("SRI_HOST_BLOCK_COLS", None)
     if args.pinned:
         import torch
 
