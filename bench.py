@@ -45,6 +45,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = "experimental_gpu_programming_for_a_spectral_numerical_integration_amd"
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -91,6 +92,8 @@ def parse(argv=None):
                     help="bracket every n-th launch of the timed region with a HIP event pair (kernel duration for the roofline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--long-run", type=int, default=500,
+                    help="after the timed region (N = 1): at least this many back-to-back launches, reported as kernel_ms_long_run (0 disables)")
     args = ap.parse_args(argv)
     n0, r0 = CONFIGS[args.config if args.config is not None else 3]
     args.n = n0 if args.n is None else args.n
@@ -127,6 +130,22 @@ def launch_ranks(n_gpus: int, argv, script: str = None) -> int:
         print("bench.py: ranks exited 0 without a result line", file=sys.stderr)
         return 1
     return proc.returncode
+
+
+def lib_sources_sha16() -> str:
+    """sha256 (first 16 hex digits) over the sources libsri_hip.so is built from — what a committed PMC summary
+    (profiles/hbm_traffic_*.json, written by tools/summarize_profile.py) is keyed on: a summary taken with other kernel
+    sources is replayed as `traffic_stale: true` and never prices anything."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, PKG, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile")
+    files.append(os.path.join(ROOT, "include", "sri_capi.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stats(ts):
@@ -603,6 +622,23 @@ def run_rank(args, world_env) -> int:
     elapsed, kernel_ms, compute_only_ms, final_gather_ms = (float(v) for v in t)
     Xl, Yl = Xs[(args.steps - 1) % nrot], Ys[(args.steps - 1) % nrot]     # the panels of the last step
 
+    # Outside the contract's timed region (and never part of `value`): the same launch, back to back, at least 500 times
+    # and for at least ~0.25 s, one HIP-event pair around the block — so that the figure of a 10-ms driver window (K = 20
+    # launches of 0.5 ms) is backed by a long run in the same process.  Same panels as the timed steps.
+    long_run_ms = long_run_launches = None
+    if not ghost and not use_dist and args.long_run > 0:
+        est = max(kernel_ms, 1e-3)
+        long_run_launches = int(min(max(args.long_run, 250.0 / est), 20000))
+        lr = (timing_event(), timing_event())
+        record(lr[0])
+        for i in range(long_run_launches):
+            rc_ = lib.sri_apply(op._h, Xs[i % nrot].data_ptr(), rows, Ys[i % nrot].data_ptr(), rows, M, stream0)
+            if rc_ != 0:
+                raise sri.SriError(rc_, "sri_apply")
+        record(lr[1])
+        fence()
+        long_run_ms = elapsed_ms(lr[0], lr[1]) / long_run_launches
+
     # optional: one tip-state gather and one full-panel gather timed on their own (reported, never part of `value`)
     full_gather_ms = None
     tip_gather_ms = None
@@ -675,7 +711,8 @@ def run_rank(args, world_env) -> int:
         mfma_bound = n / 8.0 >= PEAK_FP64_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS
         # HBM traffic is a PMC measurement (rocprofv3 --pmc, separate passes) that cannot be taken inside this
         # process: the committed summary of tools/profile_bench.sh for the same shape is replayed and labelled.
-        traffic, traffic_source, prof_kernel_ms = None, None, None
+        traffic, traffic_source, prof_kernel_ms, traffic_stale = None, None, None, None
+        sources_sha = lib_sources_sha16()
         for name in (f"hbm_traffic_n{n}_r{rods}_{args.operator}.json", "hbm_traffic_latest.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(tp):
@@ -684,24 +721,23 @@ def run_rank(args, world_env) -> int:
                 rec = json.load(open(tp))
                 if rec.get("n") == n and rec.get("rods") == rods and rec.get("operator") == args.operator:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_stale = rec.get("lib_sources_sha16") != sources_sha
                     traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of tools/profile_bench.sh" \
-                                     f"{', ' + rec['date'] if rec.get('date') else ''}; not measured in this run)"
-                    if rec.get("rocprofv3_kernel_avg_ns"):
+                                     f"{', ' + rec['date'] if rec.get('date') else ''}; not measured in this run" \
+                                     + ("; TAKEN WITH OTHER KERNEL SOURCES than this library's" if traffic_stale else "; same kernel sources") + ")"
+                    if rec.get("rocprofv3_kernel_avg_ns") and not traffic_stale:
                         prof_kernel_ms = rec["rocprofv3_kernel_avg_ns"] * 1e-6
                     break
             except Exception:
                 traffic = None
-        # Which clock prices the roofline.  Kernels long enough to bracket: the smaller of the two HIP-event upper bounds.
-        # Kernels of a few microseconds (config 2): back-to-back launches OVERLAP (launch i+1 ramps up while launch i drains),
-        # so the launch-to-launch mean is the cost of a launch in a stream while rocprofv3's begin-to-end mean of one
-        # dispatch is longer; both are in the line and the fraction is priced with the LARGER one.
-        clock = "min(single-launch bracket, launch-to-launch), HIP events in this run"
+        # The roofline is priced with THIS run's clock, always: the smaller of the two HIP-event upper bounds for kernels long
+        # enough to bracket, the launch-to-launch mean for kernels of a few microseconds (config 2).  Back-to-back launches of
+        # such a kernel OVERLAP (launch i+1 ramps up while launch i drains), so rocprofv3's begin-to-end mean of one dispatch is
+        # longer than what a launch costs in a stream: the fraction at THAT duration — from the committed profile, and only if
+        # it was taken with this library's sources — is reported beside it (`frac_at_committed_rocprof_duration`), never as `frac`.
+        clock = "min(single-launch bracket, launch-to-launch), HIP events in this run" if per_launch_events \
+            else "launch-to-launch mean, HIP events in this run"
         priced_ms = kernel_ms
-        if not per_launch_events and prof_kernel_ms is not None and prof_kernel_ms > kernel_ms:
-            priced_ms = prof_kernel_ms
-            clock = "rocprofv3 mean dispatch duration of the committed profile (larger than this run's launch-to-launch mean)"
-        elif not per_launch_events:
-            clock = "launch-to-launch mean, HIP events in this run"
         achieved_tf = flops / (priced_ms * 1e-3) / 1e12
         achieved_gbs = alg_bytes / (priced_ms * 1e-3) / 1e9
         config_id = next((c for c, (cn, cr) in CONFIGS.items() if (cn, cr) == (n, rods) and (c == 4) == (world == 8)), None)
@@ -729,7 +765,8 @@ def run_rank(args, world_env) -> int:
                        "cus_reserved_for_collective": reserve},
             # AI = N/8 flop/B against the machine balance 78.6 TF / 8 TB/s = 9.8 flop/B: HBM-bound below N ~ 79
             "roofline": roof |
-                        {"traffic": traffic, "traffic_source": traffic_source, "achieved_TFLOPs": achieved_tf,
+                        {"traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
+                         "lib_sources_sha16": sources_sha, "achieved_TFLOPs": achieved_tf,
                          "kernel_ms": priced_ms, "kernel_ms_clock": clock,
                          "kernel_ms_method": "min of two HIP-event upper bounds over the timed region: "
                                              + ((f"bracket of every {stride}th launch (mean of {len(events)})" if stride > 1 else "bracket of every launch (mean)")
@@ -738,6 +775,13 @@ def run_rank(args, world_env) -> int:
                          "kernel_ms_single_launch_bracket": bracket_ms if per_launch_events else None,
                          "kernel_ms_launch_to_launch": back_to_back_ms,
                          "kernel_ms_rocprofv3_committed": prof_kernel_ms,
+                         "frac_at_committed_rocprof_duration": (None if prof_kernel_ms is None else
+                                                                (flops / (prof_kernel_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS if mfma_bound
+                                                                 else alg_bytes / (prof_kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)),
+                         "kernel_ms_long_run": long_run_ms, "long_run_launches": long_run_launches,
+                         "frac_long_run": (None if not long_run_ms else
+                                           (flops / (long_run_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS if mfma_bound
+                                            else alg_bytes / (long_run_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)),
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_algorithmic_GBps": achieved_gbs,

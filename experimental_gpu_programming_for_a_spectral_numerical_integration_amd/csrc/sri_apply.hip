@@ -106,6 +106,10 @@ inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_asc
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
 #endif
 // A/B knobs of the tile end (tools/ab_apply.py; every combination gives bit-identical results):
+#ifndef SRI_TAIL_ABL
+#define SRI_TAIL_ABL 0               // timing-only ablations of the odd-row-count variants (tools/ab_tail.sh; results are WRONG when non-zero):
+#endif                               //   1 = no LDS write in tail_fix_fast, 2 = tail stages wait like any other, 4 = plain stores on half-empty waves,
+                                     //   8 = every operator takes the TAIL instantiation (with 2: results stay right when rows % 16 == 0)
 #ifndef SRI_STORE_SADDR
 #define SRI_STORE_SADDR 1            // 1: full tiles store through `global_store_dwordx4 v_off, v[..], s[base:base+1] offset:imm` —
 #endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
@@ -258,6 +262,22 @@ __device__ __forceinline__ d2 pack2(double lo, double hi) {
   return d2{a, b};
 #else
   return d2{lo, hi};
+#endif
+}
+
+// The value the lane ABOVE holds, inside each row of 16 lanes (a quarter-wave = the 16 row pairs of one column): lane c gets
+// `hi` of lane c - 1, lane 0 gets `wrap` of lane 15.  Two DPP moves per 32-bit half, no LDS, no exec games.
+// Used by the Y stores of a wave whose last row does not exist (255, 1023, 63 ... rows): see store_tile.
+__device__ __forceinline__ double row_above(double wrap, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long long w = __builtin_bit_cast(long long, wrap), h = __builtin_bit_cast(long long, hi);
+  int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(w), 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(lo, static_cast<int>(h), 0x111 /* row_shr:1: lane 0 keeps `old` */, 0xf, 0xf, false);
+  int up = __builtin_amdgcn_update_dpp(0, static_cast<int>(w >> 32), 0x121, 0xf, 0xf, false);
+  up = __builtin_amdgcn_update_dpp(up, static_cast<int>(h >> 32), 0x111, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (static_cast<long long>(up) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
+#else
+  return wrap + hi;
 #endif
 }
 
@@ -922,7 +942,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // Every column of the tile exists and this WAVE's 64 rows do too, except possibly the very last one (255, 1023, ...
       // rows): NSTORE 16-byte stores, straight-line, no vector-ALU address arithmetic (store16_sv).  Decided per wave —
       // the counted waits are per wave as well.
-      const bool odd = rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows + 1;        // wave-uniform: the last row pair is half empty
+      const bool odd = (SRI_TAIL_ABL & 4) == 0 && rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows + 1;   // wave-uniform: the last row pair is half empty
       const size_t ldy8 = q.ldy * sizeof(double);
       char* const ybase = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16)) * ldy8 +
                           (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
@@ -939,12 +959,18 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             }
             static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
               constexpr int t = decltype(tc)::value;
-              const d2 v = pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]);
               if constexpr (ODD && t == TM / 2 - 1) {
-                if (c != 15) store16_sv<NT, 256 * t>(cb, ylane, v);
-                else store8_sv<256 * t>(cb, ylane, v[0]);                         // the lane that holds the last row
+                // The wave's last row pair is half empty (lane 15 holds row rows - 1 and a row that does not exist).  Every
+                // lane stores its pair shifted UP by one row instead: {row 2c - 1 (from the lane above; lane 0: the last row
+                // of the previous pair), row 2c} at its usual address - 8.  Still one 16-byte store per lane, all 64 lanes, 256
+                // contiguous bytes per quarter-wave; the one row written twice (by this store and the previous pair's) gets
+                // the same value.  (Round 3 stored 16 bytes from 15 lanes and 8 from the last under exec masks: 48 store
+                // instructions and ~190 basic blocks on these waves, the slowest of their workgroup at every tile end.)
+                static_assert(TM / 2 >= 2, "needs a previous row pair in the same wave");
+                const double above = row_above(acc[2 * t - 1][tn][r], acc[2 * t + 1][tn][r]);
+                store16_sv<NT, 256 * t - 8>(cb, ylane, pack2(above, acc[2 * t][tn][r]));
               } else {
-                store16_sv<NT, 256 * t>(cb, ylane, v);
+                store16_sv<NT, 256 * t>(cb, ylane, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
               }
             });
           }
@@ -1097,16 +1123,38 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // them in the columns of its OWN X pieces — zero, or x_base[col] in the slot FOLD uses (from the side buffer its own
   // DMA filled) — after its own vmcnt wait and BEFORE the stage's barrier: one lane per column, one 8-byte ds_write per
   // slot (one slot for the N - 1 = 255, 1023, ... rows of the integration operators), no extra barrier.
+  // Layout of the write, fixed for the whole kernel (two registers): lane -> (column lc of this wave's own X pieces, slot
+  // sl): the wave's CW columns x 64 / CW tail slots per instruction, slot k = min(tail_k + sl, 15) — lanes past the last
+  // slot write slot 15 once more (same value, same address: harmless), so there is no exec mask and, for rows % 16 >=
+  // 16 - 64 / CW (every N = 2^p grid: rows % 16 = 15), no loop and nothing to fetch: round 3 re-read tail_k from the kernarg
+  // segment here — a scalar-load latency in front of the barrier of every tile's last stage.
+  constexpr int CW = 8 * (DMA ? G::X_DMA_PER_WAVE : 1), SPI = 64 / CW;
+  uint32_t tail_addr = 0, tail_more = 0, tail_head = 0;
+  if constexpr (DMA && TAIL) {
+    const uint32_t lc = static_cast<uint32_t>(lane) % CW, sl = static_cast<uint32_t>(lane) / CW;
+    const uint32_t cc = (wid + (lc >> 3) * NW) * 8 + (lc & 7);
+    const uint32_t kk = p.tail_k + sl < static_cast<uint32_t>(BK) ? p.tail_k + sl : static_cast<uint32_t>(BK) - 1;
+    tail_addr = G::A_BYTES + cc * X_ROW_BYTES + (((kk >> 1) ^ ((cc >> 1) & SWZ)) * 16) + (kk & 1) * 8;
+    tail_more = (static_cast<uint32_t>(BK) - p.tail_k + SPI - 1) / SPI - 1;      // wave-uniform, kept in a VGPR: further rounds of SPI slots
+    tail_head = kk == p.tail_k ? 1u : 0u;                       // this lane writes slot k = rows (where FOLD puts x_base) — also the
+    asm volatile("" : "+v"(tail_addr), "+v"(tail_more), "+v"(tail_head));   // clamped lanes when rows % 16 = 15: same value, same address
+  }
   auto tail_fix_fast = [&](uint32_t slot) __attribute__((always_inline)) {
-    const uint32_t tail_k = p.tail_k;                        // (resident: a reload here would put a scalar-load latency in front of the barrier)
-    if (lane < 8 * G::X_DMA_PER_WAVE) {
-      const int cc = (wid + (lane >> 3) * NW) * 8 + (lane & 7);
-      char* const colp = smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES;
-      const int sw = (cc >> 1) & SWZ;
-      double v0 = 0.0;
-      if constexpr (XBUF) v0 = *reinterpret_cast<const double*>(xb_side + (tseq_c & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES + lane * 8);
-      for (uint32_t kk = tail_k; kk < static_cast<uint32_t>(BK); ++kk) {
-        *reinterpret_cast<double*>(colp + (((kk >> 1) ^ sw) * 16) + (kk & 1) * 8) = (FOLD && kk == tail_k) ? v0 : 0.0;
+    const uint32_t lc = static_cast<uint32_t>(lane) % CW;
+    double v0 = 0.0;
+    if constexpr (XBUF) {
+      v0 = *reinterpret_cast<const double*>(xb_side + (tseq_c & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES + lc * 8);
+      v0 = tail_head != 0u ? v0 : 0.0;
+    }
+    *reinterpret_cast<double*>(smem + slot * G::STAGE_BYTES + tail_addr) = v0;
+    const uint32_t more = __builtin_amdgcn_readfirstlane(tail_more);
+    if (more != 0) {                                            // rows % 16 < 16 - SPI: rare shapes, may take their time
+      const uint32_t tail_k = p.tail_k, sl = static_cast<uint32_t>(lane) / CW;
+      const uint32_t cc = (wid + (lc >> 3) * NW) * 8 + (lc & 7);
+      for (uint32_t r = 1; r <= more; ++r) {
+        uint32_t kk = tail_k + sl + r * SPI;
+        kk = kk < static_cast<uint32_t>(BK) ? kk : static_cast<uint32_t>(BK) - 1;
+        *reinterpret_cast<double*>(smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES + (((kk >> 1) ^ ((cc >> 1) & SWZ)) * 16) + (kk & 1) * 8) = 0.0;
       }
     }
   };
@@ -1130,14 +1178,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       }
     };
     if constexpr (DMA && TAIL) {
-      if (fix_fast) {
+      if (fix_fast && (SRI_TAIL_ABL & 2) == 0) {
         if (decltype(refill_tag)::value) {
           if (since_store < static_cast<uint32_t>(AHEAD)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_BOUNDARY) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_STEADY) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        tail_fix_fast(slot);                                // this wave's own pieces have landed: rewrite its columns' tail slots
+        if constexpr ((SRI_TAIL_ABL & 1) == 0) tail_fix_fast(slot);   // this wave's own pieces have landed: rewrite its columns' tail slots
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1523,7 +1571,7 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   }
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
-  const bool tail = args.tail_k != 0;
+  const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
   if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
     if (args.nk >= 3) {
       if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);

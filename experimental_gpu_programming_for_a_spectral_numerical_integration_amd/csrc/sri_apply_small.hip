@@ -253,6 +253,12 @@ void small_pack(const double* A, size_t lda, std::vector<double>& out) {
               const int k = 16 * kc + k_of_paired(j, l >> 4, e);
               out[o] = A[row + static_cast<size_t>(k) * lda];
             }
+#ifdef SRI_TEST_CORRUPT_OPERATOR
+  // `make broken` only (never in libsri_hip.so) — as in pack_operator() of sri_apply.hip: every dispatch path of the
+  // deliberately wrong library is wrong, also the one-tile kernel a small batch takes
+  for (double& v : out)
+    if (v != 0.0) { v *= 1.0 + 0x1p-20; break; }
+#endif
 }
 
 int small_prepare(int dev) {

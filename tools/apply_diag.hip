@@ -20,10 +20,10 @@
 
 using namespace sri;
 
-template <class G, bool DMA, bool STAMP, int ABL = 0>
+template <class G, bool DMA, bool STAMP, int ABL = 0, bool TAIL = false>
 static float time_kernel(ApplyArgs a, size_t col_tiles, int reps, float* min_ms = nullptr) {
   a.col_tiles = (uint32_t)col_tiles;
-  auto kern = apply_kernel<G, DMA, false, false, STAMP, ABL>;
+  auto kern = apply_kernel<G, DMA, false, TAIL, STAMP, ABL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int per_cu = 0;
@@ -131,7 +131,17 @@ int main(int argc, char** argv) {
     case 128: ms = time_kernel<GeoTall, true, true, 128>(a, col_tiles, 5, &mn); break;
     case 32: ms = time_kernel<GeoTall, true, true, 32>(a, col_tiles, 5, &mn); break;
     case 64: ms = time_kernel<GeoTall, true, true, 64>(a, col_tiles, 5, &mn); break;
-    default: ms = time_kernel<GeoTall, true, true>(a, col_tiles, 5, &mn); break;
+    default:
+      // DIAG_TAIL=1: the odd-row-count (TAIL) instantiation on the same operator (tail_k = 0: its fix-up zeroes k slots of the
+      // last chunk — results are wrong, every address stays inside the stage's LDS image) — where does ITS extra time sit?
+      if (getenv("DIAG_TAIL") && atoi(getenv("DIAG_TAIL")) != 0) {
+        ms = time_kernel<GeoTall, true, false, 0, true>(a, col_tiles, 20, &mn);
+        printf("TAIL instantiation, unstamped : mean %.4f ms (min %.4f)\n", ms, mn);
+        ms = time_kernel<GeoTall, true, true, 0, true>(a, col_tiles, 5, &mn);
+      } else {
+        ms = time_kernel<GeoTall, true, true>(a, col_tiles, 5, &mn);
+      }
+      break;
   }
   printf("stamped (ablation %d) : mean %.4f ms (min %.4f)\n", diag_abl, ms, mn);
   std::vector<unsigned long long> s(8 * blocks);

@@ -87,6 +87,7 @@ if "hbm_bytes_per_launch" in summary and line is not None:
            "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
            "rocprofv3_kernel_avg_ns": summary.get("avg_ns"), "rocprofv3_kernel_calls": summary.get("calls"),
            "date": datetime.date.today().isoformat(),
+           "lib_sources_sha16": line["roofline"].get("lib_sources_sha16"),   # bench.py replays this record only for the same sources
            "source": f"profiles/{tag}_rocprofv3_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"}
     json.dump(rec, open(os.path.join(prof, f"hbm_traffic_n{cfg['N']}_r{cfg['rods_per_gpu']}_{cfg['operator']}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(prof, f"{tag}_rocprofv3_summary.json"), "w"), indent=1)
