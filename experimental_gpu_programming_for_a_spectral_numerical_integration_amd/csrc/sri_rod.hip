@@ -588,12 +588,14 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // iteration and, if the update is <= tol or the budget is spent, raises the stop word and returns; every later launch
   // returns at once when the word is set.  (Round 2 ran a one-block control kernel between the steps: 12-46 launches of
   // 5.5 us per solve.)  The host therefore enqueues whole chunks of iterations without waiting, keeps two chunks in
-  // flight (8 iterations each; 2 after a predicted start), and only reads back the 32-byte loop state per chunk: no host
+  // flight (8 iterations each; 1 after a predicted start), and only reads back the 32-byte loop state per chunk: no host
   // round trip sits between two iterations, and the launches enqueued past convergence cost a few microseconds each.
   // Once the loop has stopped, Q = Dnn^-1 G - w q0^T is formed by the plain integration apply and the criterion is
   // CONFIRMED on the whole panel:  max |1/2 A(K) Q - G|  bounds the next update of every entry of Q, because
   // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
-  const uint32_t kChunk = predicted ? 2u : 8u;                  // iterations enqueued per read-back of the loop state
+  // (after a predicted start the loop usually stops after ONE real step: chunks of one keep the launches past convergence at
+  // two — the step that folds and decides, and the one already in flight — instead of three with chunks of two)
+  const uint32_t kChunk = predicted ? 1u : 8u;                  // iterations enqueued per read-back of the loop state
   double* bufs[2] = {cur, nxt};                                 // iteration k reads bufs[k & 1], writes bufs[(k + 1) & 1]
   unsigned long long* const h_state = h->h_state;               // 2 slots x 4 words, pinned; owned by the handle
   hipEvent_t* const done = h->done;
