@@ -144,12 +144,12 @@ struct Geo {
   // FOLD on the LDS-DMA path (sri_integrate of an operator with rows % 16 != 0): the x_base value of each of the tile's
   // columns travels with the tile's first stage into a small buffer at the very end of the LDS allocation — 256 bytes per
   // wave (the columns of that wave's own X pieces), two tiles in flight.
-  static constexpr int XB_WAVE_BYTES = 256;
+  static constexpr int XB_WAVE_BYTES = 8 * X_DMA_PER_WAVE * 8 > 256 ? 8 * X_DMA_PER_WAVE * 8 : 256;
   static constexpr int XB_BYTES = 2 * NW * XB_WAVE_BYTES;
   static_assert(8 * X_DMA_PER_WAVE * 8 <= XB_WAVE_BYTES, "one 8-byte entry per column of the wave's X pieces");
-  static_assert(LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024, "ring + side buffers exceed a CU");
-  static_assert(P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 && (P1_BYTES + 1023) / 1024 + 1 <= NW,
-                "P1 slab and previous tips: at most one (half or whole) 1-KiB DMA piece per wave");
+  // the fused quaternion epilogue's side buffers: only geometries that satisfy this may be instantiated with EPI_QUAT
+  static constexpr bool QUAT_OK = LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
+                                  (P1_BYTES + 1023) / 1024 + 1 <= NW;   // P1 slab and previous tips: at most one 1-KiB DMA piece per wave
   static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
@@ -180,7 +180,8 @@ struct ApplyArgs {
   unsigned long long fold_max_iter;
   unsigned long long* state;
   size_t ldx, ldy, m;    // m = number of columns
-  uint32_t rows;         // valid rows of A (= valid k)
+  uint32_t rows;         // valid k (= rows of the whole operator)
+  uint32_t rows_out;     // valid output rows of THIS launch: the operator's rows, or the rows of one part of it (y, w, leg1 point at the part's first row)
   uint32_t nk;           // k chunks
   uint32_t row_blocks;
   uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
@@ -383,6 +384,7 @@ template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL 
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   constexpr bool ASCK = ASC;
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
+  static_assert(EPI == EPI_NONE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
   // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
@@ -841,8 +843,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     const size_t col0_c = static_cast<size_t>(tile % q.col_tiles) * G::BN;
     const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
     const size_t col_base4 = col0_c + wn * (TN * 16) + 4 * g;
-    const bool all_rows = rb_c * G::BM + G::BM <= q.rows;
-    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows + 1);
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows_out;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows_out + 1);
     const bool tip_lane = q.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
     const char* side = smem + G::LDS_BYTES + (tseq_c % q.side_bufs) * G::SIDE_BYTES;
     const bool monitor = q.partial != nullptr && rb_c == 0 && wm == 0;         // wave-uniform
@@ -900,11 +902,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double* yp = q.y + (col + r) * q.ldy + row;
-          if (full ? (all_rows || row + 1 < q.rows) : (DMA && row + 1 < q.rows)) {
+          if (full ? (all_rows || row + 1 < q.rows_out) : (DMA && row + 1 < q.rows_out)) {
             *reinterpret_cast<d2*>(yp) = d2{gq[0][r], gq[1][r]};
           } else {
-            if (row < q.rows) yp[0] = gq[0][r];
-            if (!full && row + 1 < q.rows) yp[1] = gq[1][r];
+            if (row < q.rows_out) yp[0] = gq[0][r];
+            if (!full && row + 1 < q.rows_out) yp[1] = gq[1][r];
           }
         }
       }
@@ -929,8 +931,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     // "full": every column of the tile exists and at most the very last row of the row block is missing
     // (rows = 255, 1023, 63, ...).  Then every wave issues at least NSTORE store instructions, which is
     // what the counted waits of the stage stream rely on.
-    const bool all_rows = rb_c * G::BM + G::BM <= q.rows;
-    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows + 1);
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows_out;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows_out + 1);
     if ((ABL & 4) != 0 || ((ABL & 32) != 0 && wid < NW / 2) || ((ABL & 64) != 0 && wid >= NW / 2)) {
       // ablation: keep the accumulators live, store nothing
 #pragma unroll
@@ -938,11 +940,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
       return false;
-    } else if (SADDR_STORES && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows + 1)) {
+    } else if (SADDR_STORES && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + (TM / 2 >= 2 ? 1 : 0))) {
       // Every column of the tile exists and this WAVE's 64 rows do too, except possibly the very last one (255, 1023, ...
       // rows): NSTORE 16-byte stores, straight-line, no vector-ALU address arithmetic (store16_sv).  Decided per wave —
       // the counted waits are per wave as well.
-      const bool odd = (SRI_TAIL_ABL & 4) == 0 && rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows + 1;   // wave-uniform: the last row pair is half empty
+      const bool odd = (SRI_TAIL_ABL & 4) == 0 && rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1;   // wave-uniform: the last row pair is half empty
       const size_t ldy8 = q.ldy * sizeof(double);
       char* const ybase = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16)) * ldy8 +
                           (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
@@ -966,8 +968,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 // contiguous bytes per quarter-wave; the one row written twice (by this store and the previous pair's) gets
                 // the same value.  (Round 3 stored 16 bytes from 15 lanes and 8 from the last under exec masks: 48 store
                 // instructions and ~190 basic blocks on these waves, the slowest of their workgroup at every tile end.)
-                static_assert(TM / 2 >= 2, "needs a previous row pair in the same wave");
-                const double above = row_above(acc[2 * t - 1][tn][r], acc[2 * t + 1][tn][r]);
+                // (geometries with one row pair per wave never come here with a half-empty pair: see the branch condition)
+                const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
                 store16_sv<NT, 256 * t - 8>(cb, ylane, pack2(above, acc[2 * t][tn][r]));
               } else {
                 store16_sv<NT, 256 * t>(cb, ylane, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 v0 -= wv[t][0] * xbv;
                 v1 -= wv[t][1] * xbv;
               }
-              if (all_rows || row + 1 < q.rows) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
+              if (all_rows || row + 1 < q.rows_out) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
               else *yp = v0;                                                                 // the lane holding the last row
             }
           }
@@ -1030,14 +1032,14 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             const uint32_t row = row_base + 32 * t;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
             if constexpr (RANK1_EPI) {
-              if (row < q.rows) v0 -= q.w[row] * xbv;
-              if (row + 1 < q.rows) v1 -= q.w[row + 1] * xbv;
+              if (row < q.rows_out) v0 -= q.w[row] * xbv;
+              if (row + 1 < q.rows_out) v1 -= q.w[row + 1] * xbv;
             }
-            if (DMA && row + 1 < q.rows) {
+            if (DMA && row + 1 < q.rows_out) {
               *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
             } else {
-              if (row < q.rows) ycol[row] = v0;
-              if (row + 1 < q.rows) ycol[row + 1] = v1;
+              if (row < q.rows_out) ycol[row] = v0;
+              if (row + 1 < q.rows_out) ycol[row + 1] = v1;
             }
           }
         }
@@ -1440,8 +1442,16 @@ using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring,
 // 4 % behind the tall geometry: 0.531 vs 0.509 ms.)
 using GeoMid = Geo<2, 2, 4, 4, 2>;
 using GeoFlat = Geo<1, 4, 4, 1, 3>;   // BM  64 x BN  64, 4 waves,  48 KiB ring, 3 WG/CU : rows <= 64 (N = 16, 64)
+// BM 64 x BN 256, 4 waves of 64 x 64 side by side (GeoMid's wave tile, MFMA : fragment-read ratio and two-slot ring, 80 KiB,
+// 2 WG per CU): the LAST 1-64 rows of an operator whose row count is not a whole number of 128- / 256-row blocks, as a part
+// of its own (round 4, "Parts" below) — a 64-row block at the larger geometries' efficiency instead of a 128- or 256-row
+// block that is mostly padding.  Plain and rank-1-epilogue launches only.
+using GeoWide = Geo<1, 4, 4, 4, 2>;
+// BM 32 x BN 256: the same for a last part of at most 32 rows — half the MFMAs of GeoWide per column tile; it streams the
+// panel at the copy rate (8 flop per byte), which is the floor of any separate launch over the last rows
+using GeoWide32 = Geo<1, 4, 2, 4, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2 };
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4 };
 
 }  // namespace sri
 
@@ -1449,8 +1459,9 @@ namespace sri {
 
 // `w` (optional, rows % 16 != 0 only): the rank-1 factor, packed negated as operator column k = rows — the free slot of
 // the last k chunk; the kernel puts x_base[col] (or 0 for a plain apply) into the matching slot of the X image.
+// `A` points at the first of `rows` rows to pack (the whole operator, or one part of it: "Parts" below); all `kdim` columns.
 template <class G>
-static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                           std::vector<double>& out) {
   out.assign(static_cast<size_t>(row_blocks) * nk * G::BM * BK, 0.0);
   size_t o = 0;
@@ -1462,8 +1473,8 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t n
             for (int e = 0; e < 2; ++e, ++o) {
               const uint32_t row = rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15);
               const uint32_t k = kc * BK + k_of(asc, j, l >> 4, e);
-              if (row < rows && k < rows) out[o] = A[row + static_cast<size_t>(k) * lda];
-              else if (w != nullptr && row < rows && k == rows) out[o] = -w[row];
+              if (row < rows && k < kdim) out[o] = A[row + static_cast<size_t>(k) * lda];
+              else if (w != nullptr && row < rows && k == kdim) out[o] = -w[row];
             }
 #ifdef SRI_TEST_CORRUPT_OPERATOR
   // `make broken` only (never in libsri_hip.so): one operator entry off by 2^-20 relative, so that a test can show
@@ -1531,6 +1542,17 @@ static int prepare_geometry(int dev) {
   return rc;
 }
 
+// GeoWide serves plain and rank-1-epilogue launches of an operator's last part only
+template <class GW>
+static int prepare_wide(int dev) {
+  int rc = prepare<GW, true, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GW, true, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GW, true, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GW, true, false, false, EPI_NONE, 0, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GW, true, false, true, EPI_NONE, 0, true>(dev);
+  return rc;
+}
+
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
 template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
@@ -1591,6 +1613,22 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
                         : launch<G, true, false, false>(args, col_tiles, dev, cus, cap, stream);
   return rank1 ? launch<G, false, true, false>(args, col_tiles, dev, cus, cap, stream)
                : launch<G, false, false, false>(args, col_tiles, dev, cus, cap, stream);
+}
+
+template <class GeoWide>
+static int dispatch_wide(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) {
+  const size_t col_tiles = (args.m + GeoWide::BN - 1) / GeoWide::BN;
+  const int cus = h->num_cus, dev = h->device;
+  const uint32_t cap = h->max_workgroups;
+  const bool tail = args.tail_k != 0;
+  if (h->ascending) {
+    if (rank1) return SRI_EUNSUPPORTED;
+    return tail ? launch<GeoWide, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
+                : launch<GeoWide, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
+  }
+  if (rank1) return tail ? SRI_EUNSUPPORTED : launch<GeoWide, true, true, false>(args, col_tiles, dev, cus, cap, stream);   // (run() keeps such handles whole)
+  return tail ? launch<GeoWide, true, false, true>(args, col_tiles, dev, cus, cap, stream)
+              : launch<GeoWide, true, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
 static const char* kernel_name(int geo, bool dma, bool quat = false) {
@@ -1677,9 +1715,9 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   std::vector<double> packed;
   try {
     const double* wf = (rows % BK != 0) ? w_host : nullptr;
-    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, h->nk, h->row_blocks, wf, false, packed);
-    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
-    else pack_operator<GeoTall>(A, lda, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
+    if (h->geo == GEO_FLAT) pack_operator<GeoFlat>(A, lda, rows, rows, h->nk, h->row_blocks, wf, false, packed);
+    else if (h->geo == GEO_MID) pack_operator<GeoMid>(A, lda, rows, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
+    else pack_operator<GeoTall>(A, lda, rows, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
   } catch (const std::bad_alloc&) {
     delete h;
     return SRI_ENOMEM;
@@ -1688,6 +1726,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     if (h->d_apack) (void)hipFree(h->d_apack);
     if (h->d_apack_small) (void)hipFree(h->d_apack_small);
     if (h->d_w) (void)hipFree(h->d_w);
+    for (sri_apply_handle::Part& part : h->parts)
+      if (part.d_apack) (void)hipFree(part.d_apack);
     delete h;
     return code;
   };
@@ -1708,8 +1748,61 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   if (hipMalloc(&h->d_apack, packed.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
   if (hipMemcpy(h->d_apack, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
     return fail(SRI_EHIP);
+  // Parts (round 4).  Rows are tiled in blocks of 256 / 128 / 64 and a partly empty block costs a full one; with one geometry
+  // per operator a row count of 64 U - r (U 64-row units) is padded to a whole number of 128- or 256-row blocks.  When
+  // U = 4a + 1 (rows 257-320, 513-576, 1025-1088, ...) the first 256a rows go to the 256-row geometry and the last 1-64 rows
+  // to a 64 x 256 part of their own (GeoWide); when U = 3 (129-192 rows) the first 128 rows go to the 128-row geometry.  Each
+  // part is a launch of the same kernel on the rows it owns (ApplyArgs::rows_out; all k): same k order, same chain of fused
+  // multiply-adds per output element — bit-identical to the single-geometry result.  The second launch re-reads the panel
+  // (from the Infinity Cache as far as it reaches), which is why thinner last parts do not pay (DESIGN.md §4 "Other grid sizes").
+  // SRI_APPLY_NO_PARTS=1 keeps every operator whole (A/B, tests).
+  {
+    const uint32_t units = (rows + 63) / 64;
+    const char* no_parts = std::getenv("SRI_APPLY_NO_PARTS");
+    int main_geo = -1;
+    uint32_t main_rows = 0;
+    if (!(no_parts && no_parts[0] == '1')) {
+      if (units >= 5 && units % 4 == 1) { main_geo = GEO_TALL; main_rows = 256 * (units / 4); }
+      else if (units == 3) { main_geo = GEO_MID; main_rows = 128; }
+    }
+    if (main_geo >= 0) {
+      rc = main_geo == GEO_TALL ? prepare_geometry<GeoTall>(device) : prepare_geometry<GeoMid>(device);
+      if (rc == SRI_OK) rc = (rows - main_rows <= GeoWide32::BM) ? prepare_wide<GeoWide32>(device) : prepare_wide<GeoWide>(device);
+      if (rc != SRI_OK) return fail(rc);
+      const double* wf = (rows % BK != 0) ? w_host : nullptr;
+      h->parts[0].geo = main_geo;
+      h->parts[0].row0 = 0;
+      h->parts[0].rows = main_rows;
+      h->parts[0].row_blocks = main_rows / (main_geo == GEO_TALL ? GeoTall::BM : GeoMid::BM);
+      h->parts[1].geo = (rows - main_rows <= GeoWide32::BM) ? GEO_WIDE32 : GEO_WIDE;
+      h->parts[1].row0 = main_rows;
+      h->parts[1].rows = rows - main_rows;
+      h->parts[1].row_blocks = 1;
+      for (int i = 0; i < 2; ++i) {
+        sri_apply_handle::Part& part = h->parts[i];
+        std::vector<double> pk;
+        try {
+          const double* Ap = A + part.row0;
+          const double* wp = wf != nullptr ? wf + part.row0 : nullptr;
+          if (part.geo == GEO_TALL) pack_operator<GeoTall>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
+          else if (part.geo == GEO_MID) pack_operator<GeoMid>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
+          else if (part.geo == GEO_WIDE) pack_operator<GeoWide>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
+          else pack_operator<GeoWide32>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
+        } catch (const std::bad_alloc&) {
+          return fail(SRI_ENOMEM);
+        }
+        if (hipMalloc(&part.d_apack, pk.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+        if (hipMemcpy(part.d_apack, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+      }
+      h->num_parts = 2;
+      const bool thin = h->parts[1].geo == GEO_WIDE32;
+      h->parts_name = main_geo == GEO_TALL ? (thin ? "sri_apply_mfma_f64<256x128,dma>+<32x256,dma>" : "sri_apply_mfma_f64<256x128,dma>+<64x256,dma>")
+                                           : (thin ? "sri_apply_mfma_f64<128x128,dma>+<32x256,dma>" : "sri_apply_mfma_f64<128x128,dma>+<64x256,dma>");
+    }
+  }
   if (w_host != nullptr) {
-    const size_t padded = static_cast<size_t>(h->row_blocks) * h->bm;
+    size_t padded = static_cast<size_t>(h->row_blocks) * h->bm;
+    if (h->num_parts != 0) padded = std::max<size_t>(padded, static_cast<size_t>(h->parts[1].row0) + GeoWide::BM);
     if (hipMalloc(&h->d_w, padded * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
     if (hipMemset(h->d_w, 0, padded * sizeof(double)) != hipSuccess) return fail(SRI_EHIP);                  // (zero padding)
     if (hipMemcpy(h->d_w, w_host, rows * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
@@ -1771,6 +1864,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.ldy = ldy;
   args.m = M;
   args.rows = h->rows;
+  args.rows_out = h->rows;
   args.nk = h->nk;
   args.row_blocks = h->row_blocks;
   args.col_tiles = 0;   // set by launch()
@@ -1791,6 +1885,28 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.tail_k = h->rows % 16;
   // (many panels: their bases are only known on the device — plain stores)
   args.nt_stores = (many == nullptr && ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
+  // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
+  // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
+  if (h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(rank1 && args.tail_k != 0) &&
+      static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32)) {
+    h->last_kernel.store(h->parts_name, std::memory_order_relaxed);
+    for (int i = 0; i < h->num_parts; ++i) {
+      const sri_apply_handle::Part& part = h->parts[i];
+      ApplyArgs a = args;
+      a.apack = part.d_apack;
+      a.y = dY + part.row0;
+      a.w = h->d_w != nullptr ? h->d_w + part.row0 : nullptr;
+      a.rows_out = part.rows;
+      a.row_blocks = part.row_blocks;
+      a.tips = part.row0 == 0 ? d_tips : nullptr;                 // the tip node is row 0
+      a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
+      rc = part.geo == GEO_WIDE ? dispatch_wide<GeoWide>(h, a, rank1, stream)
+           : part.geo == GEO_WIDE32 ? dispatch_wide<GeoWide32>(h, a, rank1, stream)
+                                : (part.geo == GEO_MID ? dispatch<GeoMid>(h, a, dma, rank1, stream) : dispatch<GeoTall>(h, a, dma, rank1, stream));
+      if (rc != SRI_OK) return rc;
+    }
+    return SRI_OK;
+  }
   h->last_kernel.store(kernel_name(h->geo, dma, quat != nullptr), std::memory_order_relaxed);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
   if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);
@@ -1916,6 +2032,8 @@ int sri_apply_destroy(sri_apply_t* h) {
   if (h->d_apack) (void)hipFree(h->d_apack);
   if (h->d_apack_small) (void)hipFree(h->d_apack_small);
   if (h->d_w) (void)hipFree(h->d_w);
+  for (sri_apply_handle::Part& part : h->parts)
+    if (part.d_apack) (void)hipFree(part.d_apack);
   sri::host_pipe_destroy(h->pipe);   // sri_host_panels.hip
   delete h;
   return SRI_OK;

@@ -128,6 +128,17 @@ struct sri_apply_handle {
   double* d_apack_small = nullptr;   // 64-row operators: fragment order of sri_apply_small.hip (small plain applies take that kernel)
   double* d_w = nullptr;        // Dnn_inv * Din (padded), for sri_integrate
   bool ascending = false;       // k order of this handle's launches (see kAscendingAboveRows)
+  // "Parts" (sri_apply.hip): for plain and rank-1-epilogue launches the operator may be cut into a main part and a last part
+  // of its own geometry (rows [row0, row0 + rows), all k), each packed and launched separately on the caller's stream.
+  // num_parts == 0: one geometry for the whole operator (always what the fused step and sri_apply_many use).
+  struct Part {
+    int geo = 0;
+    uint32_t row0 = 0, rows = 0, row_blocks = 0;
+    double* d_apack = nullptr;
+  };
+  Part parts[2];
+  int num_parts = 0;
+  const char* parts_name = "none";
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use
   int host_copy_threads = -1;      // CPU threads that move a host panel into / out of the pinned staging slots; -1 = default

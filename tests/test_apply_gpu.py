@@ -71,20 +71,35 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
     assert ("dma" in op.last_kernel) == expect_dma, op.last_kernel
 
 
+WIDE_TALL, WIDE_MID = "256x128,dma>+<64x256", "128x128,dma>+<64x256"
+THIN_TALL, THIN_MID = "256x128,dma>+<32x256", "128x128,dma>+<32x256"     # a last part of at most 32 rows
+
+
 @pytest.mark.parametrize("n,which,M,geometry", [
-    (256, 0, 300, "256x128"),        # a full 256-row block
-    (257, 0, 300, "128x128"),        # 257 ... 384 rows: three 128-row blocks instead of two 256-row ones
-    (320, 0, 700, "128x128"),
-    (321, 1, 260, "128x128"),        # the integration operator of a 321-node grid: 320 rows, initial-value term as an epilogue
-    (384, 0, 129, "128x128"),
-    (385, 0, 200, "256x128"),        # the last 256-row block is more than half full again
-    (640, 0, 140, "128x128"),        # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
-    (641, 1, 90, "128x128"),         # 640 rows, paired order (integration operator)
-    (897, 0, 70, "256x128"),
+    (256, 0, 300, "<256x128,dma>"),  # a full 256-row block
+    (257, 0, 300, THIN_TALL),        # 257 ... 320 rows (round 4): 256 rows in the tall geometry + the last 1-64 as a part of their own
+    (288, 0, 515, THIN_TALL),        # ... 32 x 256 tiles up to 32 rows, 64 x 256 above
+    (300, 1, 333, WIDE_TALL),        # 299 rows, k tail: both parts are TAIL builds, the last part's last wave is half empty
+    (320, 0, 700, WIDE_TALL),
+    (321, 1, 260, WIDE_TALL),        # the integration operator of a 321-node grid: 320 rows
+    (384, 0, 129, "<128x128,dma>"),  # 321 ... 384 rows: three 128-row blocks instead of two 256-row ones (round 3)
+    (385, 0, 200, "<256x128,dma>"),  # the last 256-row block is more than half full again
+    (513, 0, 140, THIN_TALL),        # ascending-k builds of both parts, two row blocks + one row
+    (560, 2, 150, WIDE_TALL),        # Dn_NN of a 560-node grid: 559 rows, ascending k with a k tail
+    (640, 0, 140, "<128x128,dma>"),  # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
+    (641, 1, 90, "<128x128,dma>"),   # 640 rows, paired order (integration operator)
+    (897, 0, 70, "<256x128,dma>"),
+    (1025, 0, 2100, THIN_TALL),      # four row blocks (XCD-grouped walk of the main part) + one row
+    (130, 0, 300, THIN_MID),         # 129 ... 192 rows (round 4): 128 rows in the 128-row geometry + the last 1-64
+    (160, 0, 777, THIN_MID),
+    (176, 0, 300, WIDE_MID),
+    (192, 2, 512, WIDE_MID),         # 191 rows
+    (193, 0, 100, "<256x128,dma>"),
 ])
 def test_geometry_above_256_rows(sri, oracle, n, which, M, geometry):
     """Rows are tiled in blocks of 128 or 256; above 256 rows the handle takes the 128-row geometry wherever the last
-    256-row block would be at most half full (round 3).  Same parity gate, same bit-exact model, whichever geometry runs."""
+    256-row block would be at most half full (round 3), and cuts operators of 64 (4a + 1) - r or 192 - r rows into a main part and
+    a last part of 1-64 rows with its own 64 x 256 geometry (round 4).  Same parity gate, same bit-exact model, whichever runs."""
     A = _operator_matrix(oracle, n, which)
     rows = A.shape[0]
     X = np.asfortranarray(rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M])
@@ -186,7 +201,45 @@ def test_empty_and_error_paths(sri):
     assert lib.sri_apply(op._h, good.data_ptr(), 5_000_000, good.data_ptr(), 64, 100_000, None) == -6   # SRI_EUNSUPPORTED
 
 
-@pytest.mark.parametrize("n", [16, 64, 256])
+def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
+    """An operator cut into parts (two launches, two geometries) against the same operator kept whole (SRI_APPLY_NO_PARTS=1 at
+    handle creation): Y, the tip row and sri_integrate's result must be bit-identical — also on a strided panel, where the
+    last part's columns start inside the caller's columns."""
+    import os
+    import torch
+
+    for n, which, M, ld_extra in [(300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0)]:
+        rows = n if which == 0 else n - 1
+        X = uniform_panel(rows, M, seed=n)
+        ops = []
+        for env in ("0", "1"):
+            os.environ["SRI_APPLY_NO_PARTS"] = env
+            try:
+                ops.append(sri.SpectralApply(n, which))
+            finally:
+                del os.environ["SRI_APPLY_NO_PARTS"]
+        ld = rows + ld_extra
+        Xd = torch.full((M, ld), float("nan"), dtype=torch.float64, device="cuda")
+        Xd[:, :rows] = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+        lib = sri.load_library()
+        outs = []
+        for op in ops:
+            Yd = torch.full((M, ld), -7.25, dtype=torch.float64, device="cuda")
+            tips = torch.zeros(M, dtype=torch.float64, device="cuda")
+            assert lib.sri_apply_tips(op._h, Xd.data_ptr(), ld, Yd.data_ptr(), ld, M, tips.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
+            outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
+        assert ">+<" in outs[0][2] and ">+<" not in outs[1][2], (outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
+        assert torch.equal(outs[0][1], outs[0][0][:, 0])
+        if which == 1:
+            xb = torch.rand(M, dtype=torch.float64, device="cuda")
+            ys = [op.integrate(Xd[:, :rows].contiguous(), xb) for op in ops]
+            assert torch.equal(ys[0], ys[1]), (n, "integrate")
+
+
+@pytest.mark.parametrize("n", [16, 64, 256, 300, 321])
 def test_integrate_matches_oracle(sri, oracle, n):
     """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T)."""
     import torch
@@ -213,9 +266,10 @@ def test_integrate_matches_oracle(sri, oracle, n):
     lib = oracle.lib()
     Ym = np.zeros((n - 1, M), order="F")
     assert not op.ascending_k                        # the integration operator keeps the paired order at every size
-    assert lib.sri_model_apply(oracle.MODEL_KERNEL, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
-                               Xext.ctypes.data_as(oracle._dp), n, Ym.ctypes.data_as(oracle._dp), n - 1, M) == 0
-    assert np.array_equal(Y, Ym)
+    if (n - 1) % 16 != 0:                            # (with a whole number of k chunks the term is an epilogue: product, then one subtraction)
+        assert lib.sri_model_apply(oracle.MODEL_KERNEL, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
+                                   Xext.ctypes.data_as(oracle._dp), n, Ym.ctypes.data_as(oracle._dp), n - 1, M) == 0
+        assert np.array_equal(Y, Ym)
     # backward error is measured against |Dinv| (|B| + |Din||xb|): the epilogue form reassociates the rank-1 term
     scale = np.abs(Dinv) @ (np.abs(B) + np.outer(np.abs(Din), np.abs(xb)))
     assert np.max(np.abs(Y - Yref) / scale) <= backward_tol(n)

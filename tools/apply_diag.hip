@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
 
   ApplyArgs a{};
   a.apack = h->d_apack; a.x = dX; a.y = dY; a.w = nullptr; a.xb = nullptr;
-  a.nt_stores = 1; a.ldx = n; a.ldy = n; a.m = M; a.rows = n; a.nk = h->nk; a.row_blocks = h->row_blocks; a.stamps = nullptr;
+  a.nt_stores = 1; a.ldx = n; a.ldy = n; a.m = M; a.rows = n; a.rows_out = n; a.nk = h->nk; a.row_blocks = h->row_blocks; a.stamps = nullptr;
   if (h->geo != GEO_TALL) { printf("diag is written for the tall geometry (rows > 128)\n"); return 0; }
   const size_t col_tiles = (M + GeoTall::BN - 1) / GeoTall::BN;
   int tall_per_cu = 0;
