@@ -57,6 +57,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -115,23 +116,29 @@ inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_asc
 #endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16; NSTAGE LDS ring slots.
-template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_>
+// STRIP_ = 1: one more 16-row tile of the operator per row block, below the BM rows the waves own (A_ROWS = BM + 16): a
+// 16 x BN strip of the output that the waves share, 16 columns each — the last 1-16 rows of an operator of 256 a + r rows
+// ride along with the last 256-row block, on the X stages that are in LDS anyway (round 4, "Parts").
+template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_, int STRIP_ = 0>
 struct Geo {
-  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_;
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_, STRIP = STRIP_;
   static constexpr int NW = WM * WN;
   static constexpr int THREADS = 64 * NW;
   static constexpr int WAVES_PER_SIMD = (NW + 3) / 4 < 2 ? 2 : (NW + 3) / 4;   // launch-bounds hint
   static constexpr int BM = WM * TM * 16;
   static constexpr int BN = WN * TN * 16;
-  static constexpr int A_BYTES = BM * BK * 8;
+  static constexpr int A_ROWS = BM + 16 * STRIP;
+  static constexpr int A_BYTES = A_ROWS * BK * 8;
+  static constexpr int A_STRIP_OFFSET = BM * BK * 8;                    // the strip's tile inside a stage's operator slab
+  static constexpr int A_PIECES = A_BYTES / 1024;
   static constexpr int X_BYTES = BN * BK * 8;
   static constexpr int STAGE_BYTES = A_BYTES + X_BYTES;
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
-  static constexpr int A_DMA_PER_WAVE = A_BYTES / 1024 / NW;
+  static constexpr int A_DMA_PER_WAVE = (A_PIECES + NW - 1) / NW;         // (a slab that does not split evenly: the last pieces are fetched twice)
   static constexpr int X_DMA_PER_WAVE = X_BYTES / 1024 / NW;
   static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
   static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
-  static constexpr int NSTORE = TM * TN * 2;                            // 16-byte Y stores per lane of a full tile
+  static constexpr int NSTORE = TM * TN * 2 + 4 * STRIP;                // Y store instructions per wave of a full tile (the strip: four of 8 bytes)
   // EPI_QUAT: the strain coefficients of a tile's rods (BN/4 rods x 9 doubles, contiguous in memory) travel with the
   // tile's first stage into a side buffer behind the ring; QE_BUFS tiles may be between "issued" and "epilogue read".
   // Each buffer also holds the Legendre factor P1 of the tile's BM rows.  Two buffers are enough when a tile has
@@ -148,9 +155,11 @@ struct Geo {
   static constexpr int XB_BYTES = 2 * NW * XB_WAVE_BYTES;
   static_assert(8 * X_DMA_PER_WAVE * 8 <= XB_WAVE_BYTES, "one 8-byte entry per column of the wave's X pieces");
   // the fused quaternion epilogue's side buffers: only geometries that satisfy this may be instantiated with EPI_QUAT
-  static constexpr bool QUAT_OK = LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
+  static constexpr bool QUAT_OK = STRIP == 0 && LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
                                   (P1_BYTES + 1023) / 1024 + 1 <= NW;   // P1 slab and previous tips: at most one 1-KiB DMA piece per wave
-  static_assert(A_BYTES % (1024 * NW) == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
+  static_assert(A_BYTES % 1024 == 0 && (STRIP != 0 || A_BYTES % (1024 * NW) == 0) && X_BYTES % (1024 * NW) == 0,
+                "stage must split into whole 1-KiB DMA pieces per wave");
+  static_assert(STRIP == 0 || (WM == TN && TM % 2 == 0), "the strip's BN columns are dealt 16 per wave: wave (wm, wn) takes column tile wm of its own 16 TN");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
   static_assert((AHEAD - 1) * DMA_PER_WAVE + NSTORE <= 63, "counted vmcnt must fit the 6-bit counter");
@@ -621,7 +630,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if (!(ABL & 1) || abl_first) {
 #pragma unroll
       for (int it = 0; it < G::A_DMA_PER_WAVE; ++it) {
-        const int i = wid + it * NW;
+        int i = wid + it * NW;
+        if constexpr (G::A_PIECES % NW != 0) i = i < G::A_PIECES ? i : G::A_PIECES - 1;   // (fetched twice: same bytes, same place)
         lds_dma16_sv(gA + i * 1024, aoff, sA + i * 1024);
       }
     }
@@ -659,7 +669,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if (idx == 0) { issue_qe(); issue_xb(); }
     if (idx < G::A_DMA_PER_WAVE) {
       if (!(ABL & 1) || abl_first) {
-        const int i = wid + idx * NW;
+        int i = wid + idx * NW;
+        if constexpr (G::A_PIECES % NW != 0) i = i < G::A_PIECES ? i : G::A_PIECES - 1;
         lds_dma16_sv(abase + static_cast<size_t>(kc_i) * G::A_BYTES + i * 1024, aoff, sA + i * 1024);
       }
     } else {
@@ -752,6 +763,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int e = 0; e < 2; ++e) xq[j][e] = x_off + (g & 1) * 8 + ((4 * j + 2 * e + (g >> 1)) ^ sig) * 16;
   }
 
+  // The strip (G::STRIP): one more accumulator tile per wave — rows BM .. BM + 15 of the row block, columns tile `wm` of the
+  // wave's own TN column tiles — and ONE set of fragments for it, read at the top of a k pair (behind the pair's own
+  // fragments, which are in registers by then) and consumed after the last MFMA group of each k-step: 16 registers in all.
+  d4 sacc = d4{0.0, 0.0, 0.0, 0.0};
+  d2 sfa = d2{0.0, 0.0}, sfb = d2{0.0, 0.0};
+  const int s_a_off = G::A_STRIP_OFFSET + lane * 16;
+  const int s_x_add = wm * 16 * X_ROW_BYTES;                    // from the wave's column tile 0 to its column tile wm
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
   // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
   // "groups" (k-step e, row tile tm) of TN MFMAs each.  With PIECES (steady state of the DMA build) one
@@ -790,6 +808,21 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         b[tn] = *reinterpret_cast<const d2*>(rd + tn * 16 * X_ROW_BYTES);
     }
   };
+  auto strip_read = [&](uint32_t slot, int j) __attribute__((always_inline)) {
+    if constexpr (G::STRIP != 0) {
+      const char* base = smem + slot * G::STAGE_BYTES;
+      sfa = *reinterpret_cast<const d2*>(base + s_a_off + j * 1024);
+      if constexpr (ASCK) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          sfb[e] = *reinterpret_cast<const double*>(base + xq[ASCK ? j : 0][e] + s_x_add);
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        sfb = *reinterpret_cast<const d2*>(base + xpp[j] + s_x_add);
+      }
+    }
+  };
   // groups [G0, G1) of the k pair held in (a, b); `piece` counts the DMA pieces issued so far in this body
   auto mfma_groups = [&](const d2 (&a)[TM], const d2 (&b)[TN], auto g0_tag, auto g1_tag, int& piece, auto pieces_tag)
                          __attribute__((always_inline)) {
@@ -801,6 +834,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+      if constexpr (G::STRIP != 0) {
+        if (tm == TM - 1) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sfb[e], sfa[e], sacc, 0, 0, 0);   // k-step e of the strip
+      }
       if constexpr (PIECES) {
         if (piece < G::DMA_PER_WAVE) {
           __builtin_amdgcn_sched_barrier(0);
@@ -913,6 +949,48 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
     return full;
   };
+  // The strip's 16 x 16 tile of this wave: lane (c, g) holds row BM + c of the columns g, g + 4, g + 8, g + 12 of the wave's
+  // column tile wm — four 8-byte stores, 128 contiguous bytes per column.  `counted`: every column exists and the wave is on
+  // the counted-store path: exactly four store INSTRUCTIONS must be issued whatever the number of valid rows (the stage waits
+  // count them), so the rows that do not exist are masked out through exec, not branched around.
+  auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted) __attribute__((always_inline)) {
+    if constexpr (G::STRIP != 0) {
+      const uint32_t row = rb_c * G::BM + G::BM + c;
+      const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + g;
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = sacc[r];
+        if constexpr (RANK1_EPI) {
+          if (row < q.rows_out && col_s + 4 * r < q.m) v[r] -= q.w[row] * q.xb[col_s + 4 * r];
+        }
+      }
+      if (counted) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t valid = q.rows_out - (rb_c * G::BM + G::BM);                    // 1 .. 16 rows of the strip exist
+        const uint32_t m16 = valid >= 16u ? 0xffffu : ((1u << valid) - 1u);
+        const unsigned long long mask = 0x0001000100010001ull * m16;                   // the same 16 row lanes in every quarter-wave
+        const size_t ldy8 = q.ldy * sizeof(double);
+        char* const b0 = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16) + wm * 16) * ldy8 + (static_cast<size_t>(rb_c) * G::BM + G::BM) * sizeof(double);
+        char* const b1 = b0 + 4 * ldy8;
+        char* const b2 = b1 + 4 * ldy8;
+        char* const b3 = b2 + 4 * ldy8;
+        const uint32_t off = static_cast<uint32_t>(g) * static_cast<uint32_t>(ldy8) + static_cast<uint32_t>(c) * 8u;
+        asm volatile("s_mov_b64 exec, %9\n\t"
+                     "global_store_dwordx2 %0, %1, %5\n\t"
+                     "global_store_dwordx2 %0, %2, %6\n\t"
+                     "global_store_dwordx2 %0, %3, %7\n\t"
+                     "global_store_dwordx2 %0, %4, %8\n\t"
+                     "s_mov_b64 exec, -1\n\ts_nop 1"
+                     ::"v"(off), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(mask) : "memory");
+#endif
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row < q.rows_out && col_s + 4 * r < q.m) ypanel[(col_s + 4 * r) * q.ldy + row] = v[r];
+      }
+    }
+  };
   constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && !RANK1_EPI && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
@@ -979,6 +1057,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       };
       if (q.nt_stores != 0) { if (odd) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
       else { if (odd) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
+      store_strip(q, rb_c, col0_c, ypanel, true);
       emit_tips(q, rb_c, col_base);
       return true;
     } else if (!SADDR_STORES && full) {                     // (with SADDR_STORES every tile that is `full` took the branch above)
@@ -1015,6 +1094,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           }
       };
       if (q.nt_stores != 0) emit(std::true_type{}); else emit(std::false_type{});   // same store count either way
+      store_strip(q, rb_c, col0_c, ypanel, true);
       emit_tips(q, rb_c, col_base);
       return true;
     } else {
@@ -1043,6 +1123,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             }
           }
         }
+      store_strip(q, rb_c, col0_c, ypanel, false);
       emit_tips(q, rb_c, col_base);
       return false;
     }
@@ -1220,6 +1301,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+      if constexpr (G::STRIP != 0) sacc = zero4;
     }
   };
   auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
@@ -1292,11 +1374,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
       read_pair(slot_c, 0, pa, pb);
+      strip_read(slot_c, 0);
       mfma_groups(pa, pb, I0{}, I2{}, piece, PT{});
       read_pair(slot_c, 1, qa, qb);
       if constexpr ((ABL & 8) != 0) abl_read = false;
       mfma_groups(pa, pb, I2{}, IG{}, piece, PT{});
       seg_mark(1);
+      strip_read(slot_c, 1);                                       // (one fragment set: k pair 0's last strip MFMA has been issued)
       mfma_groups(qa, qb, I0{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
       seg_mark(2);
@@ -1326,10 +1410,12 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       if constexpr (REFILL && !PIECES) stage_issue();
       int piece = 0;
       read_pair(slot_c, 0, pa, pb);
+      strip_read(slot_c, 0);
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
       read_pair(slot_c, 1, qa, qb);
       if constexpr ((ABL & 8) != 0) abl_read = false;
       mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      strip_read(slot_c, 1);                                       // for the k pair the next body starts with: read BEFORE its barrier
       flush_pieces(piece, PT{});
       if constexpr (REFILL) {
         stage_commit(rslot);
@@ -1363,9 +1449,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // measured: no gain.)  The stores follow this body's pieces in program order.
       if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
       tl_mark(K4{});
+      strip_read(slot_c, 0);                                         // (s, 0): the strip's one fragment set is free again
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
       read_pair(slot_c, 1, qa, qb);                                  // (s, 1): used at the top of the next body
       mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      strip_read(slot_c, 1);                                         // ... and so is this: issued before the next barrier frees the slot
       seg_mark(2);
       if constexpr (REFILL) {
         stage_commit(rslot);
@@ -1451,7 +1539,11 @@ using GeoWide = Geo<1, 4, 4, 4, 2>;
 // panel at the copy rate (8 flop per byte), which is the floor of any separate launch over the last rows
 using GeoWide32 = Geo<1, 4, 2, 4, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4 };
+// GeoTall + the strip: 272 x 128 per tile, 150 KiB ring — the last 256-row block of an operator of 256 a + r rows, r <= 16,
+// with those r rows riding along (+ 2 MFMAs per 32 and two fragment reads per k pair and wave): no second pass over the panel
+using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
+
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5 };
 
 }  // namespace sri
 
@@ -1463,15 +1555,17 @@ namespace sri {
 template <class G>
 static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                           std::vector<double>& out) {
-  out.assign(static_cast<size_t>(row_blocks) * nk * G::BM * BK, 0.0);
+  out.assign(static_cast<size_t>(row_blocks) * nk * G::A_ROWS * BK, 0.0);
   size_t o = 0;
   for (uint32_t rb = 0; rb < row_blocks; ++rb)
     for (uint32_t kc = 0; kc < nk; ++kc)
-      for (int tile = 0; tile < G::BM / 16; ++tile)
+      for (int tile = 0; tile < G::A_ROWS / 16; ++tile)
         for (int j = 0; j < KPAIRS; ++j)
           for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 2; ++e, ++o) {
-              const uint32_t row = rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15);
+              // (the strip's tile, if the geometry has one, follows the BM rows of its — only — row block: row slot = row)
+              const uint32_t row = tile < G::BM / 16 ? rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15)
+                                                     : rb * G::BM + G::BM + static_cast<uint32_t>(l & 15);
               const uint32_t k = kc * BK + k_of(asc, j, l >> 4, e);
               if (row < rows && k < kdim) out[o] = A[row + static_cast<size_t>(k) * lda];
               else if (w != nullptr && row < rows && k == kdim) out[o] = -w[row];
@@ -1613,6 +1707,34 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
                         : launch<G, true, false, false>(args, col_tiles, dev, cus, cap, stream);
   return rank1 ? launch<G, false, true, false>(args, col_tiles, dev, cus, cap, stream)
                : launch<G, false, false, false>(args, col_tiles, dev, cus, cap, stream);
+}
+
+static int prepare_strip(int dev) {
+  int rc = prepare<GeoTallStrip, true, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, false, EPI_NONE, 0, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, true>(dev);
+  return rc;
+}
+
+static int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) {
+  using GS = GeoTallStrip;
+  const size_t col_tiles = (args.m + GS::BN - 1) / GS::BN;
+  const int cus = h->num_cus, dev = h->device;
+  const uint32_t cap = h->max_workgroups;
+  const bool tail = args.tail_k != 0;
+  if (args.row_blocks != 1) return SRI_EUNSUPPORTED;                 // the strip belongs to its part's only row block
+  if (h->ascending) {
+    if (rank1) return SRI_EUNSUPPORTED;
+    return tail ? launch<GS, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
+                : launch<GS, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
+  }
+  if (rank1) return tail ? launch<GS, true, true, true>(args, col_tiles, dev, cus, cap, stream)
+                         : launch<GS, true, true, false>(args, col_tiles, dev, cus, cap, stream);
+  return tail ? launch<GS, true, false, true>(args, col_tiles, dev, cus, cap, stream)
+              : launch<GS, true, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
 template <class GeoWide>
@@ -1759,50 +1881,67 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   {
     const uint32_t units = (rows + 63) / 64;
     const char* no_parts = std::getenv("SRI_APPLY_NO_PARTS");
-    int main_geo = -1;
-    uint32_t main_rows = 0;
+    const char* no_strip = std::getenv("SRI_APPLY_NO_STRIP");       // A/B: thin last rows as a part of their own instead of a strip
+    int np = 0;
     if (!(no_parts && no_parts[0] == '1')) {
-      if (units >= 5 && units % 4 == 1) { main_geo = GEO_TALL; main_rows = 256 * (units / 4); }
-      else if (units == 3) { main_geo = GEO_MID; main_rows = 128; }
+      if (units >= 5 && units % 4 == 1) {
+        const uint32_t full = 256 * (units / 4), rest = rows - full;
+        if (rest <= 16 && !(no_strip && no_strip[0] == '1')) {
+          // 256 a + r rows, r <= 16: the first a - 1 row blocks as they are, the last one with the r rows as its strip
+          if (full > 256) { h->parts[np].geo = GEO_TALL; h->parts[np].row0 = 0; h->parts[np].rows = full - 256; h->parts[np].row_blocks = full / 256 - 1; ++np; }
+          h->parts[np].geo = GEO_TALL_STRIP; h->parts[np].row0 = full - 256; h->parts[np].rows = 256 + rest; h->parts[np].row_blocks = 1; ++np;
+        } else {
+          h->parts[np].geo = GEO_TALL; h->parts[np].row0 = 0; h->parts[np].rows = full; h->parts[np].row_blocks = full / 256; ++np;
+          h->parts[np].geo = rest <= GeoWide32::BM ? GEO_WIDE32 : GEO_WIDE; h->parts[np].row0 = full; h->parts[np].rows = rest; h->parts[np].row_blocks = 1; ++np;
+        }
+      } else if (units == 3) {
+        const uint32_t rest = rows - 128;
+        h->parts[np].geo = GEO_MID; h->parts[np].row0 = 0; h->parts[np].rows = 128; h->parts[np].row_blocks = 1; ++np;
+        h->parts[np].geo = rest <= GeoWide32::BM ? GEO_WIDE32 : GEO_WIDE; h->parts[np].row0 = 128; h->parts[np].rows = rest; h->parts[np].row_blocks = 1; ++np;
+      }
     }
-    if (main_geo >= 0) {
-      rc = main_geo == GEO_TALL ? prepare_geometry<GeoTall>(device) : prepare_geometry<GeoMid>(device);
-      if (rc == SRI_OK) rc = (rows - main_rows <= GeoWide32::BM) ? prepare_wide<GeoWide32>(device) : prepare_wide<GeoWide>(device);
-      if (rc != SRI_OK) return fail(rc);
+    if (np != 0) {
+      static const char* const geo_names[6] = {"<64x64,dma>", "<128x128,dma>", "<256x128,dma>", "<64x256,dma>", "<32x256,dma>", "<256+16x128,dma>"};
       const double* wf = (rows % BK != 0) ? w_host : nullptr;
-      h->parts[0].geo = main_geo;
-      h->parts[0].row0 = 0;
-      h->parts[0].rows = main_rows;
-      h->parts[0].row_blocks = main_rows / (main_geo == GEO_TALL ? GeoTall::BM : GeoMid::BM);
-      h->parts[1].geo = (rows - main_rows <= GeoWide32::BM) ? GEO_WIDE32 : GEO_WIDE;
-      h->parts[1].row0 = main_rows;
-      h->parts[1].rows = rows - main_rows;
-      h->parts[1].row_blocks = 1;
-      for (int i = 0; i < 2; ++i) {
+      h->parts_label = "sri_apply_mfma_f64";
+      for (int i = 0; i < np && rc == SRI_OK; ++i) {
         sri_apply_handle::Part& part = h->parts[i];
+        switch (part.geo) {
+          case GEO_TALL: rc = prepare_geometry<GeoTall>(device); break;
+          case GEO_MID: rc = prepare_geometry<GeoMid>(device); break;
+          case GEO_WIDE: rc = prepare_wide<GeoWide>(device); break;
+          case GEO_WIDE32: rc = prepare_wide<GeoWide32>(device); break;
+          default: rc = prepare_strip(device); break;
+        }
+        if (rc != SRI_OK) break;
         std::vector<double> pk;
         try {
           const double* Ap = A + part.row0;
           const double* wp = wf != nullptr ? wf + part.row0 : nullptr;
-          if (part.geo == GEO_TALL) pack_operator<GeoTall>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
-          else if (part.geo == GEO_MID) pack_operator<GeoMid>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
-          else if (part.geo == GEO_WIDE) pack_operator<GeoWide>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
-          else pack_operator<GeoWide32>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk);
+          switch (part.geo) {
+            case GEO_TALL: pack_operator<GeoTall>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            case GEO_MID: pack_operator<GeoMid>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            case GEO_WIDE: pack_operator<GeoWide>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            case GEO_WIDE32: pack_operator<GeoWide32>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            default: pack_operator<GeoTallStrip>(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+          }
+          h->parts_label += (i == 0 ? "" : "+");
+          h->parts_label += geo_names[part.geo];
         } catch (const std::bad_alloc&) {
           return fail(SRI_ENOMEM);
         }
         if (hipMalloc(&part.d_apack, pk.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
         if (hipMemcpy(part.d_apack, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+        if (part.geo == GEO_WIDE || part.geo == GEO_WIDE32) h->parts_have_wide = true;
       }
-      h->num_parts = 2;
-      const bool thin = h->parts[1].geo == GEO_WIDE32;
-      h->parts_name = main_geo == GEO_TALL ? (thin ? "sri_apply_mfma_f64<256x128,dma>+<32x256,dma>" : "sri_apply_mfma_f64<256x128,dma>+<64x256,dma>")
-                                           : (thin ? "sri_apply_mfma_f64<128x128,dma>+<32x256,dma>" : "sri_apply_mfma_f64<128x128,dma>+<64x256,dma>");
+      if (rc != SRI_OK) return fail(rc);
+      h->num_parts = np;
+      h->parts_name = h->parts_label.c_str();
     }
   }
   if (w_host != nullptr) {
     size_t padded = static_cast<size_t>(h->row_blocks) * h->bm;
-    if (h->num_parts != 0) padded = std::max<size_t>(padded, static_cast<size_t>(h->parts[1].row0) + GeoWide::BM);
+    if (h->num_parts != 0) padded = std::max<size_t>(padded, static_cast<size_t>(rows) + 256);
     if (hipMalloc(&h->d_w, padded * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
     if (hipMemset(h->d_w, 0, padded * sizeof(double)) != hipSuccess) return fail(SRI_EHIP);                  // (zero padding)
     if (hipMemcpy(h->d_w, w_host, rows * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
@@ -1887,7 +2026,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.nt_stores = (many == nullptr && ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
   // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
-  if (h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(rank1 && args.tail_k != 0) &&
+  if (h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
       static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32)) {
     h->last_kernel.store(h->parts_name, std::memory_order_relaxed);
     for (int i = 0; i < h->num_parts; ++i) {
@@ -1902,6 +2041,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
       rc = part.geo == GEO_WIDE ? dispatch_wide<GeoWide>(h, a, rank1, stream)
            : part.geo == GEO_WIDE32 ? dispatch_wide<GeoWide32>(h, a, rank1, stream)
+           : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream)
                                 : (part.geo == GEO_MID ? dispatch<GeoMid>(h, a, dma, rank1, stream) : dispatch<GeoTall>(h, a, dma, rank1, stream));
       if (rc != SRI_OK) return rc;
     }

@@ -112,6 +112,7 @@ int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY,
 #if defined(SRI_DEVICE_HELPERS)   /* defined by the .hip translation units after <hip/hip_runtime.h> */
 }  // namespace sri
 #include <atomic>
+#include <string>
 #include <tuple>
 #include <utility>
 
@@ -138,6 +139,8 @@ struct sri_apply_handle {
   };
   Part parts[2];
   int num_parts = 0;
+  bool parts_have_wide = false;
+  std::string parts_label;           // what sri_apply_last_kernel reports for a launch in parts
   const char* parts_name = "none";
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use

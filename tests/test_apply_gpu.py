@@ -73,23 +73,29 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
 
 WIDE_TALL, WIDE_MID = "256x128,dma>+<64x256", "128x128,dma>+<64x256"
 THIN_TALL, THIN_MID = "256x128,dma>+<32x256", "128x128,dma>+<32x256"     # a last part of at most 32 rows
+STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256 a + r rows, r <= 16: the r rows ride with the last block
 
 
 @pytest.mark.parametrize("n,which,M,geometry", [
     (256, 0, 300, "<256x128,dma>"),  # a full 256-row block
-    (257, 0, 300, THIN_TALL),        # 257 ... 320 rows (round 4): 256 rows in the tall geometry + the last 1-64 as a part of their own
+    (257, 0, 300, STRIP1),           # 257 ... 272 rows (round 4): ONE launch, the last 1-16 rows as a strip of the 256-row block
+    (258, 1, 515, STRIP1),           # 257 rows of an integration operator
+    (272, 0, 130, STRIP1),
+    (273, 0, 300, THIN_TALL),        # 273 ... 320 rows: 256 rows in the tall geometry + the last 17-64 as a part of their own:
     (288, 0, 515, THIN_TALL),        # ... 32 x 256 tiles up to 32 rows, 64 x 256 above
     (300, 1, 333, WIDE_TALL),        # 299 rows, k tail: both parts are TAIL builds, the last part's last wave is half empty
     (320, 0, 700, WIDE_TALL),
     (321, 1, 260, WIDE_TALL),        # the integration operator of a 321-node grid: 320 rows
     (384, 0, 129, "<128x128,dma>"),  # 321 ... 384 rows: three 128-row blocks instead of two 256-row ones (round 3)
     (385, 0, 200, "<256x128,dma>"),  # the last 256-row block is more than half full again
-    (513, 0, 140, THIN_TALL),        # ascending-k builds of both parts, two row blocks + one row
+    (513, 0, 140, STRIPN),           # ascending k: one plain row block + the last block with its strip        # ascending-k builds of both parts, two row blocks + one row
     (560, 2, 150, WIDE_TALL),        # Dn_NN of a 560-node grid: 559 rows, ascending k with a k tail
     (640, 0, 140, "<128x128,dma>"),  # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
     (641, 1, 90, "<128x128,dma>"),   # 640 rows, paired order (integration operator)
     (897, 0, 70, "<256x128,dma>"),
-    (1025, 0, 2100, THIN_TALL),      # four row blocks (XCD-grouped walk of the main part) + one row
+    (1025, 0, 2100, STRIPN),         # three row blocks + the last with one more row
+    (1040, 0, 300, STRIPN),          # ... with sixteen
+    (1041, 0, 300, THIN_TALL),      # four row blocks (XCD-grouped walk of the main part) + one row
     (130, 0, 300, THIN_MID),         # 129 ... 192 rows (round 4): 128 rows in the 128-row geometry + the last 1-64
     (160, 0, 777, THIN_MID),
     (176, 0, 300, WIDE_MID),
@@ -115,7 +121,7 @@ def test_mfma_layout_exact_integers(sri):
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
     Asymmetric data, as cdna_hip_programming.md §3 asks."""
     rng = np.random.default_rng(7)
-    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
+    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
@@ -208,7 +214,8 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
     import os
     import torch
 
-    for n, which, M, ld_extra in [(300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0)]:
+    for n, which, M, ld_extra in [(300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
+                                  (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
         ops = []
@@ -230,7 +237,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert ">+<" in outs[0][2] and ">+<" not in outs[1][2], (outs[0][2], outs[1][2])
+        assert (">+<" in outs[0][2] or "256+16" in outs[0][2]) and ">+<" not in outs[1][2] and "256+16" not in outs[1][2], (outs[0][2], outs[1][2])
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
         assert torch.equal(outs[0][1], outs[0][0][:, 0])
         if which == 1:

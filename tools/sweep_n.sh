@@ -5,7 +5,7 @@ tag=${1:-r04}
 out=gpurun_out/${tag}_sweep_n.jsonl
 : > $out
 for n in ${SWEEP_NS:-32 48 64 96 128 160 192 256 257 300 320 384 512 513 576 640 768 896 1024 1025 1088}; do
-  rods=$(python3 -c "print(max(64, (2**29 // ($n * 8 * 4)) // 16 * 16))")
+  rods=$(python3 -c "print(max(64, (2**29 // ($n * 8 * 4)) // 32 * 32))")
   timeout -k 10 120 python bench.py --n $n --rods $rods --steps 300 --warmup 30 --ramp-ms 600 --cpu-seconds 0 --no-verify --long-run 0 >> $out 2>> gpurun_out/${tag}_sweep_n.err || echo "{\"n\": $n, \"failed\": true}" >> $out
 done
 python3 - <<PY
