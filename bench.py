@@ -92,6 +92,9 @@ def parse(argv=None):
                     help="bracket every n-th launch of the timed region with a HIP event pair (kernel duration for the roofline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--ld", type=int, default=0,
+                    help="leading dimension of the panels in doubles (default: the operator's row count; e.g. 256 for the 255-row "
+                         "integration operator: columns on whole 128-byte lines, INTEGRATION.md §2).  Single-GPU runs only.")
     ap.add_argument("--long-run", type=int, default=500,
                     help="after the timed region (N = 1): at least this many back-to-back launches, reported as kernel_ms_long_run (0 disables)")
     args = ap.parse_args(argv)
@@ -481,8 +484,18 @@ def run_rank(args, world_env) -> int:
         X = Y = None
     else:
         Xs = [device_panel(torch, n, rows, rods, args.data, 0x5EED + rank + 1000 * r, dev) for r in range(nrot)]
-        Ys = [torch.empty_like(Xs[0]) for _ in range(nrot)]
+        if args.ld > rows:                                  # strided panels: `ld` doubles per column, NaN between the columns
+            def padded(t):
+                buf = torch.full((t.shape[0], args.ld), float("nan"), dtype=torch.float64, device=dev)
+                buf[:, :rows] = t
+                return buf[:, :rows]
+            Xs = [padded(x) for x in Xs]
+        Ys = [torch.empty_like(Xs[0]) if args.ld <= rows else torch.empty((M, args.ld), dtype=torch.float64, device=dev)[:, :rows]
+              for _ in range(nrot)]
         X, Y = Xs[0], Ys[0]
+    ld = args.ld if args.ld > rows else rows
+    if ld != rows and use_dist:
+        raise SystemExit("bench.py: --ld is a single-GPU option")
 
     # exchange step (N > 1): tips of step i gathered on a side stream under the apply of step i+1
     comm_stream = torch.cuda.Stream(device=dev) if (use_dist and not ghost) else None
@@ -520,9 +533,9 @@ def run_rank(args, world_env) -> int:
             # otherwise, and N > 1 must not pay more per step than N = 1 does)
             k = i % nrot
             if use_dist and args.gather == "final":
-                rc = lib.sri_apply_tips(op._h, Xs[k].data_ptr(), rows, Ys[k].data_ptr(), rows, M, tips_local[i & 1].data_ptr(), stream0)
+                rc = lib.sri_apply_tips(op._h, Xs[k].data_ptr(), ld, Ys[k].data_ptr(), ld, M, tips_local[i & 1].data_ptr(), stream0)
             else:
-                rc = lib.sri_apply(op._h, Xs[k].data_ptr(), rows, Ys[k].data_ptr(), rows, M, stream0)
+                rc = lib.sri_apply(op._h, Xs[k].data_ptr(), ld, Ys[k].data_ptr(), ld, M, stream0)
             if rc != 0:
                 raise sri.SriError(rc, "sri_apply")
             return
@@ -533,7 +546,12 @@ def run_rank(args, world_env) -> int:
             torch.cuda.current_stream().wait_event(gathered[b])       # tip buffer b free again
         if ev_pair is not None:
             ev_pair[0].record()
-        op.apply(Xi, out=Yi, tips=tips_local[b] if tip_mode else None)  # the epilogue emits the tip state itself
+        if ld != rows:                                          # (the Python mirror takes contiguous panels)
+            rc = lib.sri_apply(op._h, Xi.data_ptr(), ld, Yi.data_ptr(), ld, M, stream0)
+            if rc != 0:
+                raise sri.SriError(rc, "sri_apply")
+        else:
+            op.apply(Xi, out=Yi, tips=tips_local[b] if tip_mode else None)  # the epilogue emits the tip state itself
         if ev_pair is not None:
             ev_pair[1].record()
         if use_dist and args.gather == "tip":
@@ -550,7 +568,10 @@ def run_rank(args, world_env) -> int:
     t_ramp = time.perf_counter()
     while not ghost and (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
         for _ in range(20):
-            op.apply(X, out=Y)
+            if ld != rows:
+                lib.sri_apply(op._h, X.data_ptr(), ld, Y.data_ptr(), ld, M, stream0)
+            else:
+                op.apply(X, out=Y)
         torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
@@ -632,7 +653,7 @@ def run_rank(args, world_env) -> int:
         lr = (timing_event(), timing_event())
         record(lr[0])
         for i in range(long_run_launches):
-            rc_ = lib.sri_apply(op._h, Xs[i % nrot].data_ptr(), rows, Ys[i % nrot].data_ptr(), rows, M, stream0)
+            rc_ = lib.sri_apply(op._h, Xs[i % nrot].data_ptr(), ld, Ys[i % nrot].data_ptr(), ld, M, stream0)
             if rc_ != 0:
                 raise sri.SriError(rc_, "sri_apply")
         record(lr[1])
@@ -713,13 +734,14 @@ def run_rank(args, world_env) -> int:
         # process: the committed summary of tools/profile_bench.sh for the same shape is replayed and labelled.
         traffic, traffic_source, prof_kernel_ms, traffic_stale = None, None, None, None
         sources_sha = lib_sources_sha16()
-        for name in (f"hbm_traffic_n{n}_r{rods}_{args.operator}.json", "hbm_traffic_latest.json"):
+        ld_tag = "" if ld == rows else f"_ld{ld}"
+        for name in (f"hbm_traffic_n{n}_r{rods}_{args.operator}{ld_tag}.json", "hbm_traffic_latest.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(tp):
                 continue
             try:
                 rec = json.load(open(tp))
-                if rec.get("n") == n and rec.get("rods") == rods and rec.get("operator") == args.operator:
+                if rec.get("n") == n and rec.get("rods") == rods and rec.get("operator") == args.operator and rec.get("ld", rows) == ld:
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_stale = rec.get("lib_sources_sha16") != sources_sha
                     traffic_source = f"profiles/{name} (rocprofv3 --pmc passes of tools/profile_bench.sh" \
@@ -757,7 +779,7 @@ def run_rank(args, world_env) -> int:
                                    + ("synthetic rod-strain fields" if args.data == "rod" else "uniform U[-1,1) panels")
                                    + (f", {world} GPUs sharded on the batch axis, RCCL all-gather of {args.gather} state" if use_dist else ""),
                        "baseline_config": config_id,
-                       "N": n, "rods_per_gpu": rods, "state_columns": 4, "operator": args.operator,
+                       "N": n, "rods_per_gpu": rods, "state_columns": 4, "operator": args.operator, "ld": ld,
                        "panel_data": args.data, "panel_pairs_rotated": nrot,
                        "kernel": op.last_kernel, "gather": args.gather if use_dist else "none",
                        "collective": collective,

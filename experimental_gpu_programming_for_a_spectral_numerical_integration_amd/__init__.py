@@ -54,6 +54,7 @@ C_ABI = {
     "sri_integrate_tips": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp]),
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
     "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
+    "sri_apply_set_lean_tail": (_int, [_vp, _int]),
     "sri_apply_set_host_copy_threads": (_int, [_vp, _int]),
     "sri_apply_set_host_memory_pinned": (_int, [_vp, _int]),
     "sri_apply_destroy": (_int, [_vp]),
@@ -376,6 +377,11 @@ class SpectralApply:
             raise ValueError("out must have as many columns as B")
         _chk(load_library().sri_integrate_host(self._h, _p(B), ldb, _p(xb), _p(Y), ldy, M), "sri_integrate_host")
         return Y
+
+    def set_lean_tail(self, enable: bool) -> None:
+        """Odd-row-count operators: allow (default) or forbid the kernel variants that read the panel's last column up to its
+        last k chunk's end where that cannot fault (``sri_apply_set_lean_tail``); same results either way."""
+        _chk(load_library().sri_apply_set_lean_tail(self._h, 1 if enable else 0), "sri_apply_set_lean_tail")
 
     def set_host_copy_threads(self, threads: int) -> None:
         """CPU threads that move host panels into / out of the handle's pinned staging slots (-1 = default, 0 = caller only)."""

@@ -371,6 +371,9 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           8-byte stores: any rows / ld / M / alignment.
 //   RANK1 : epilogue subtracts w[row]*xb[col] (the initial-value term of main.cpp:162-164,172).
 //   TAIL  : rows % 16 != 0 (DMA builds): safe source addresses + LDS fix-up for the last k chunk of a tile.
+//   LEAN  : a TAIL build WITHOUT the safe source addresses of the panel's last column (its last chunk is fetched where it lies,
+//           up to 16 - rows % 16 elements past the column's end, like every other column's): launched only where run() has
+//           checked that those bytes share their 4-KiB page with the panel's last valid byte — see run().
 //   STAMP : diagnostic only — lane 0 of each workgroup records shader-clock / real-time stamps.
 //   ABL   : diagnostic only (tools/apply_diag.hip) — ablation mask, results are WRONG when non-zero:
 //           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
@@ -389,7 +392,7 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 // ---------------------------------------------------------------------------------------------
 enum { EPI_NONE = 0, EPI_QUAT = 1 };
 
-template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false>
+template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false, bool LEAN = false>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   constexpr bool ASCK = ASC;
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       const size_t last_col = q.m - 1;
       const size_t left = last_col - col0_i;                      // columns of the panel behind the tile's first one
       const uint32_t lim = left < static_cast<size_t>(G::BN) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(G::BN);
-      edge_i = left < static_cast<size_t>(G::BN);
+      edge_i = !LEAN && left < static_cast<size_t>(G::BN);
       tail_base0 = false;
 #pragma unroll
       for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // Only the LAST column of the panel needs that: behind every other column lies the next one (or the padding of a
         // strided panel), so the piece can be fetched where it is — its valid element arrives by DMA like any other and
         // fixup_tail() only overwrites the foreign one.
-        if constexpr (TAIL) xsafe[it] = (cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(q.tail_k)) ? X_ROW_BYTES : 0;
+        if constexpr (TAIL) xsafe[it] = (!LEAN && cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(q.tail_k)) ? X_ROW_BYTES : 0;
       }
     }
   };
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // (ct_c == last column tile, kept by advance_compute(): a `tile % col_tiles` here is a dozen vector-ALU
       // instructions — hipcc divides on the float pipe — and was if-converted into EVERY stage: -2.5 %)
       if (kc_s + 1 == p.nk) {
-        fix_edge = ct_c + 1 == p.col_tiles;
+        fix_edge = !LEAN && ct_c + 1 == p.col_tiles;
         fix_fast = !fix_edge;
       }
     }
@@ -1584,7 +1587,7 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t k
 // Written under prepare()'s lock (handles may be created from several host threads, on the same or on different
 // devices), read lock-free by launch().
 constexpr int kMaxDevices = 16;
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
 static std::atomic<int>& residency(int dev) {
   static std::atomic<int> blocks_per_cu[kMaxDevices] = {};
   return blocks_per_cu[dev];
@@ -1595,13 +1598,13 @@ static std::mutex& prepare_mutex() {
   return m;
 }
 
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
 static int prepare(int dev) {
   if (dev < 0 || dev >= kMaxDevices) return SRI_EUNSUPPORTED;
-  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
   std::lock_guard<std::mutex> lock(prepare_mutex());
-  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
-  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
+  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>;
   constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : 0;        // FOLD on the LDS-DMA path: x_base side buffer at the end
   constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
@@ -1610,7 +1613,7 @@ static int prepare(int dev) {
   SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
   int nb = 0;
   SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
-  residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
+  residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
   return SRI_OK;
 }
 
@@ -1628,6 +1631,12 @@ static int prepare_geometry(int dev) {
   }
   if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
   if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
+  if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
+    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_NONE, 0, false, true>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true, true>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2, false, true>(dev);
+  }
   if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
     if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 4>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 4>(dev);
@@ -1649,10 +1658,10 @@ static int prepare_wide(int dev) {
 
 // Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
 // than there are tiles.
-template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false>
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
 static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream,
                   uint32_t* partials = nullptr) {
-  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC>(dev).load(std::memory_order_acquire);
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_acquire);
   if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
   const size_t tiles = col_tiles * args.row_blocks * (args.panels != 0 ? args.panels : 1u);
   if (tiles == 0) return SRI_OK;
@@ -1671,23 +1680,34 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     *partials = grid * G::WN;
   }
   constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + ((DMA && RANK1 && TAIL) ? G::XB_BYTES : 0);
-  SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC>), dim3(grid), dim3(G::THREADS), lds, stream, args));
+  SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>), dim3(grid), dim3(G::THREADS), lds, stream, args));
   return SRI_OK;
 }
 
+// `lean`: run() has established that the panel's last column may be read up to its last k chunk's end (LEAN twins exist for the
+// 128- and 256-row geometries; the 64-row one is HBM-bound either way).
 template <class G>
-static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr) {
+static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr, bool lean = false) {
   const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
-  if constexpr (G::BM >= 128) {
-    if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
-      if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;
-      return args.tail_k != 0 ? launch<G, true, false, true, EPI_NONE, 0, true>(args, col_tiles, h->device, h->num_cus, h->max_workgroups, stream)
-                              : launch<G, true, false, false, EPI_NONE, 0, true>(args, col_tiles, h->device, h->num_cus, h->max_workgroups, stream);
-    }
-  }
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
+  if constexpr (G::BM >= 128) {
+    if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
+      if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;
+      if (tail && lean) return launch<G, true, false, true, EPI_NONE, 0, true, true>(args, col_tiles, dev, cus, cap, stream);
+      return tail ? launch<G, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
+                  : launch<G, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
+    }
+    if (dma && tail && lean) {
+      if (args.qe != nullptr) {
+        if (args.nk >= 3) return launch<G, true, true, true, EPI_QUAT, 2, false, true>(args, col_tiles, dev, cus, cap, stream, partials);
+      } else {
+        return rank1 ? launch<G, true, true, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
+                     : launch<G, true, false, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream);
+      }
+    }
+  }
   if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
     if (args.nk >= 3) {
       if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
@@ -1716,10 +1736,13 @@ static int prepare_strip(int dev) {
   if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, true>(dev);
   if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, false, EPI_NONE, 0, true>(dev);
   if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, true, EPI_NONE, 0, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, true, true>(dev);
   return rc;
 }
 
-static int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) {
+static int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean) {
   using GS = GeoTallStrip;
   const size_t col_tiles = (args.m + GS::BN - 1) / GS::BN;
   const int cus = h->num_cus, dev = h->device;
@@ -1728,9 +1751,12 @@ static int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hip
   if (args.row_blocks != 1) return SRI_EUNSUPPORTED;                 // the strip belongs to its part's only row block
   if (h->ascending) {
     if (rank1) return SRI_EUNSUPPORTED;
+    if (tail && lean) return launch<GS, true, false, true, EPI_NONE, 0, true, true>(args, col_tiles, dev, cus, cap, stream);
     return tail ? launch<GS, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
                 : launch<GS, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
   }
+  if (tail && lean) return rank1 ? launch<GS, true, true, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
+                                 : launch<GS, true, false, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream);
   if (rank1) return tail ? launch<GS, true, true, true>(args, col_tiles, dev, cus, cap, stream)
                          : launch<GS, true, true, false>(args, col_tiles, dev, cus, cap, stream);
   return tail ? launch<GS, true, false, true>(args, col_tiles, dev, cus, cap, stream)
@@ -1753,7 +1779,7 @@ static int dispatch_wide(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipS
               : launch<GeoWide, true, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
-static const char* kernel_name(int geo, bool dma, bool quat = false) {
+static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean = false) {
   static const char* names[3][4] = {
       {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<64x64,reg,quat>",
        "sri_apply_mfma_f64<64x64,dma,quat>"},
@@ -1761,6 +1787,11 @@ static const char* kernel_name(int geo, bool dma, bool quat = false) {
        "sri_apply_mfma_f64<128x128,dma,quat>"},
       {"sri_apply_mfma_f64<256x128,reg>", "sri_apply_mfma_f64<256x128,dma>", "sri_apply_mfma_f64<256x128,reg,quat>",
        "sri_apply_mfma_f64<256x128,dma,quat>"}};
+  // (the lean twins of the odd-row-count variants: 128- and 256-row geometries, LDS-DMA builds)
+  static const char* lean_names[3][2] = {{"", ""},
+                                         {"sri_apply_mfma_f64<128x128,dma,lean>", "sri_apply_mfma_f64<128x128,dma,quat,lean>"},
+                                         {"sri_apply_mfma_f64<256x128,dma,lean>", "sri_apply_mfma_f64<256x128,dma,quat,lean>"}};
+  if (lean && dma && geo != GEO_FLAT) return lean_names[geo][quat ? 1 : 0];
   return names[geo][(dma ? 1 : 0) + (quat ? 2 : 0)];
 }
 
@@ -1937,6 +1968,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       if (rc != SRI_OK) return fail(rc);
       h->num_parts = np;
       h->parts_name = h->parts_label.c_str();
+      h->parts_label_lean = h->parts_label + ",lean";
+      h->parts_name_lean = h->parts_label_lean.c_str();
     }
   }
   if (w_host != nullptr) {
@@ -2024,11 +2057,23 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.tail_k = h->rows % 16;
   // (many panels: their bases are only known on the device — plain stores)
   args.nt_stores = (many == nullptr && ldy % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 128 == 0) ? 1u : 0u;
+  // The odd-row-count kernels fetch the last k chunk of every column where it lies: for the panel's LAST column that reaches up
+  // to 16 - rows % 16 elements past the column's end.  The edge-safe variants step those pieces back and rebuild the image from
+  // bounds-checked loads — logic that is dormant in every tile but one and still costs the instantiation 12-30 spilled scalar
+  // registers and 1.6 % on identical work (round 4: profiles/r04_ab_tail_lean.log).  Memory protection is page-granular (4 KiB at
+  // least): if the bytes past the end lie in the SAME page as the panel's last valid byte they can be read, whatever they hold
+  // (tail_fix_fast overwrites their LDS image before any MFMA sees it) — then, and only then, the LEAN twin runs (same bits).
+  bool lean = false;
+  if (dma && args.tail_k != 0 && many == nullptr) {
+    const uintptr_t end = reinterpret_cast<uintptr_t>(dX + (M - 1) * ldx + h->rows);      // one past the last valid byte
+    const uintptr_t over = (16u - args.tail_k) * sizeof(double);
+    lean = h->lean_tail && ((end - 1) >> 12) == ((end + over - 1) >> 12);
+  }
   // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
   if (h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
       static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32)) {
-    h->last_kernel.store(h->parts_name, std::memory_order_relaxed);
+    h->last_kernel.store(lean ? h->parts_name_lean : h->parts_name, std::memory_order_relaxed);
     for (int i = 0; i < h->num_parts; ++i) {
       const sri_apply_handle::Part& part = h->parts[i];
       ApplyArgs a = args;
@@ -2041,16 +2086,17 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
       rc = part.geo == GEO_WIDE ? dispatch_wide<GeoWide>(h, a, rank1, stream)
            : part.geo == GEO_WIDE32 ? dispatch_wide<GeoWide32>(h, a, rank1, stream)
-           : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream)
-                                : (part.geo == GEO_MID ? dispatch<GeoMid>(h, a, dma, rank1, stream) : dispatch<GeoTall>(h, a, dma, rank1, stream));
+           : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream, lean)
+                                : (part.geo == GEO_MID ? dispatch<GeoMid>(h, a, dma, rank1, stream, nullptr, lean)
+                                                       : dispatch<GeoTall>(h, a, dma, rank1, stream, nullptr, lean));
       if (rc != SRI_OK) return rc;
     }
     return SRI_OK;
   }
-  h->last_kernel.store(kernel_name(h->geo, dma, quat != nullptr), std::memory_order_relaxed);
+  h->last_kernel.store(kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
   if (h->geo == GEO_FLAT) return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials);
-  if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials);
-  return dispatch<GeoTall>(h, args, dma, rank1, stream, partials);
+  if (h->geo == GEO_MID) return dispatch<GeoMid>(h, args, dma, rank1, stream, partials, lean);
+  return dispatch<GeoTall>(h, args, dma, rank1, stream, partials, lean);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
@@ -2127,6 +2173,12 @@ int sri_apply_create_matrix(sri_apply_t** out, uint32_t rows, const double* A, s
 int sri_apply_set_max_workgroups(sri_apply_t* h, uint32_t max_workgroups) {
   if (h == nullptr) return SRI_EINVAL;
   h->max_workgroups = max_workgroups;
+  return SRI_OK;
+}
+
+int sri_apply_set_lean_tail(sri_apply_t* h, int enable) {
+  if (h == nullptr) return SRI_EINVAL;
+  h->lean_tail = enable != 0;
   return SRI_OK;
 }
 

@@ -142,6 +142,9 @@ struct sri_apply_handle {
   bool parts_have_wide = false;
   std::string parts_label;           // what sri_apply_last_kernel reports for a launch in parts
   const char* parts_name = "none";
+  std::string parts_label_lean;
+  const char* parts_name_lean = "none";
+  bool lean_tail = true;             // odd-row-count operators: take the lean kernels where run() finds them safe (sri_apply_set_lean_tail)
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use
   int host_copy_threads = -1;      // CPU threads that move a host panel into / out of the pinned staging slots; -1 = default

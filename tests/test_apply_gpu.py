@@ -111,7 +111,7 @@ def test_geometry_above_256_rows(sri, oracle, n, which, M, geometry):
     X = np.asfortranarray(rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M])
     op = sri.SpectralApply(n, which)
     Y = _run(op, X)
-    assert geometry in op.last_kernel, op.last_kernel
+    assert geometry in op.last_kernel.replace(",lean", ""), op.last_kernel      # (",lean": which twin of an odd-row-count kernel ran)
     assert op.ascending_k == (rows > 512 and which != 1)
     assert_apply_parity(oracle, A, X, Y, n, what=(n, which, M, op.last_kernel), ascending=op.ascending_k, kind="rod", which=which)
 
@@ -244,6 +244,50 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             xb = torch.rand(M, dtype=torch.float64, device="cuda")
             ys = [op.integrate(Xd[:, :rows].contiguous(), xb) for op in ops]
             assert torch.equal(ys[0], ys[1]), (n, "integrate")
+
+
+def test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides(sri):
+    """Odd-row-count operators have two kernel variants: one that reads the panel's LAST column up to the end of its last k
+    chunk (a few doubles past the column; never used) and one that never reads past the panel.  The launch takes the first only
+    where those bytes share their 4-KiB page with the panel's last valid byte.  Same bits; the rule is checked with the panel
+    placed so that it ends exactly on a page boundary (edge-safe kernel), so that the bytes past its end just cross into the next
+    page (edge-safe), and in the middle of a page (lean)."""
+    import torch
+
+    lib = sri.load_library()
+    for n, which, M in [(256, 1, 3000), (1024, 2, 600), (300, 0, 1500), (258, 1, 1111), (128, 1, 5000)]:
+        op = sri.SpectralApply(n, which)
+        rows = op.rows
+        over = (16 - rows % 16) * 8
+        pool = torch.zeros(rows * M + 4096, dtype=torch.float64, device="cuda")
+        pool[:] = torch.rand(pool.shape, dtype=torch.float64, device="cuda") * 2 - 1
+        base = pool.data_ptr()
+        results = {}
+        for name, end_mod in (("page end", 0), ("crossing", 4096 - over + 8), ("mid page", 2048)):
+            # first element offset such that (base + 8 off + 8 rows M) % 4096 == end_mod
+            off = ((end_mod - base - 8 * rows * M) % 4096) // 8
+            assert (base + 8 * off + 8 * rows * M) % 4096 == end_mod % 4096
+            X = pool[off:off + rows * M].view(M, rows)
+            Y = torch.empty((M, rows), dtype=torch.float64, device="cuda")
+            assert lib.sri_apply(op._h, X.data_ptr(), rows, Y.data_ptr(), rows, M, None) == 0
+            torch.cuda.synchronize()
+            kernel = op.last_kernel
+            expect_lean = name == "mid page"
+            assert ("lean" in kernel) == expect_lean, (n, which, name, kernel)
+            op.set_lean_tail(False)
+            Y2 = torch.empty_like(Y)
+            assert lib.sri_apply(op._h, X.data_ptr(), rows, Y2.data_ptr(), rows, M, None) == 0
+            torch.cuda.synchronize()
+            assert "lean" not in op.last_kernel
+            op.set_lean_tail(True)
+            assert torch.equal(Y, Y2), (n, which, name)
+            results[name] = (X.clone(), Y)
+        # the same numbers at three placements give the same result
+        Xm, Ym = results["mid page"]
+        Yd = torch.empty_like(Ym)
+        assert lib.sri_apply(op._h, Xm.data_ptr(), rows, Yd.data_ptr(), rows, M, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Yd, Ym)
 
 
 @pytest.mark.parametrize("n", [16, 64, 256, 300, 321])

@@ -123,6 +123,56 @@ def test_fused_quaternion_step(sri, oracle, n, rods):
     assert rel <= 1e-12, rel
 
 
+def test_fused_step_lean_and_edge_safe_kernels_agree(sri):
+    """The fused step of an N = 2^p grid (255, 127, 1023 rows) has the same two variants as the plain odd-row-count apply
+    (tests/test_apply_gpu.py::test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides): same bits."""
+    import torch
+
+    for n, rods in [(256, 1500), (128, 900), (512, 300)]:
+        m = n - 1
+        g = torch.Generator(device="cuda").manual_seed(n)
+        qe = torch.rand((rods, 9), dtype=torch.float64, device="cuda", generator=g) * 4 - 2
+        q0 = torch.randn((rods, 4), dtype=torch.float64, device="cuda", generator=g)
+        pool = torch.rand((rods * 4 * m + 1024,), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+        off = ((2048 - pool.data_ptr() - 8 * rods * 4 * m) % 4096) // 8          # the panel ends in the middle of a page
+        G = pool[off:off + rods * 4 * m].view(rods, 4, m)
+        rod = sri.RodIntegrator(n)
+        a = rod.quaternion_step(qe, G, q0)
+        integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+        integ.set_lean_tail(False)
+        Q = integ.integrate(G.reshape(rods * 4, m), q0.reshape(-1)).reshape(rods, 4, m)
+        ref = rod.quaternion_rhs(rod.strain_field(qe), Q)
+        torch.cuda.synchronize()
+        assert torch.equal(a, ref), n
+
+
+def test_fused_step_on_the_xcd_grouped_tile_walk(sri):
+    """N = 1024 with 2 048 rods on the streaming path: four row blocks and 64 column tiles on a full grid — the one shape class
+    where the fused step (EPI_QUAT: tip rows, convergence monitor and side buffers all assume row block 0 / tile sequence)
+    runs under the XCD-grouped tile walk of round 3 (tile_order = 1).  Bit-identical to the unfused composition (whose plain
+    apply walks the same way and is pinned to the oracle by test_full_config5), tips and monitor exact."""
+    import torch
+
+    n, rods = 1024, 2048
+    m = n - 1
+    g = torch.Generator(device="cuda").manual_seed(77)
+    qe = torch.rand((rods, 9), dtype=torch.float64, device="cuda", generator=g) * 4 - 2
+    G = torch.rand((rods, 4, m), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    q0 = torch.randn((rods, 4), dtype=torch.float64, device="cuda", generator=g)
+    tips_prev = torch.randn((rods, 4), dtype=torch.float64, device="cuda", generator=g)
+    rod = sri.RodIntegrator(n)
+    tips = torch.full((rods, 4), float("nan"), dtype=torch.float64, device="cuda")
+    update = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    Gn = rod.quaternion_step(qe, G, q0, tips=tips, tips_prev=tips_prev, update=update)
+    integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+    Q = integ.integrate(G.reshape(rods * 4, m), q0.reshape(-1)).reshape(rods, 4, m)
+    ref = rod.quaternion_rhs(rod.strain_field(qe), Q)
+    torch.cuda.synchronize()
+    assert torch.equal(Gn, ref)
+    assert torch.equal(tips, Q[:, :, 0])
+    assert update.view(torch.float64).item() == (tips - tips_prev).abs().max().item()
+
+
 def test_large_batch_properties(sri):
     """N=256, 4096 rods: too many for the dense oracle — check invariants of the exact solution instead."""
     import torch

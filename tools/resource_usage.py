@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 txt = open(os.path.join(ROOT, "build/asm/resource_usage.txt")).read()
 isa = open(os.path.join(ROOT, "build/asm/sri_apply-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-GEO = {"1": "flat 64x64   Geo<1,4,4,1,3>", "2": "mid  128x128 Geo<2,2,4,4,2>", "4": "tall 256x128 Geo<4,2,4,4,3>"}
+GEO = {"1,4,4,1,3,0": "flat 64x64   Geo<1,4,4,1,3>", "2,2,4,4,2,0": "mid  128x128 Geo<2,2,4,4,2>", "4,2,4,4,3,0": "tall 256x128 Geo<4,2,4,4,3>",
+       "1,4,4,4,2,0": "wide 64x256  Geo<1,4,4,4,2>", "1,4,2,4,2,0": "wide 32x256  Geo<1,4,2,4,2>", "4,2,4,4,3,1": "strip 272x128 Geo<4,2,4,4,3,1>"}
 SCR, OCC = r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
 out = ["# Register / spill / occupancy report of every shipped variant of sri::apply_kernel (csrc/sri_apply.hip).",
        "# `make -C <pkg>/csrc asm` (hipcc -Rpass-analysis=kernel-resource-usage, --offload-arch=gfx950) + tools/resource_usage.py.",
@@ -22,7 +23,10 @@ out = ["# Register / spill / occupancy report of every shipped variant of sri::a
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = b.split("\n")[0].split(" ")[0]
     g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
-    m = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)", name)
+    mg = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEE", name)
+    m = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi\dEEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)", name)
+    if mg is None or m is None:
+        continue
     i = isa.index(name + ":")
     body = isa[i:isa.index(".Lfunc_end", i)]
     lane = valu = steady_lane = 0
@@ -46,7 +50,7 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
             if t and not t.startswith((";", ".")):
                 cur.append(t)
     flush(cur)
-    out.append(f"{GEO[m.group(1)]:28s} {m.group(6):>3s} {m.group(7):>2s} {m.group(8):>4s} {m.group(11):>3s} {m.group(12):>3s} | "
+    out.append(f"{GEO.get(','.join(mg.groups()), ','.join(mg.groups())):28s} {m.group(6):>3s} {m.group(7):>2s} {m.group(8):>4s} {m.group(11):>3s} {m.group(12):>3s} | "
                f"{g('VGPRs'):>4s} {g('TotalSGPRs'):>4s} {g('SGPRs Spill'):>6s} {g('VGPRs Spill'):>6s} {g(SCR):>7s} {g(OCC):>3s} | "
                f"{lane:4d} / {valu:4d} | {steady_lane}")
 text = "\n".join(out) + "\n"

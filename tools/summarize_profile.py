@@ -83,12 +83,15 @@ if "hbm_bytes_per_launch" in summary and line is not None:
     cfg = line["config"]
     alg = line["roofline"]["algorithmic_bytes_per_launch"]
     summary["hbm_bytes_over_algorithmic"] = summary["hbm_bytes_per_launch"] / alg
-    rec = {"n": cfg["N"], "rods": cfg["rods_per_gpu"], "operator": cfg["operator"],
+    rows_ = cfg["N"] if cfg["operator"] == "dn" else cfg["N"] - 1
+    ld_ = cfg.get("ld", rows_)
+    ld_tag = "" if ld_ == rows_ else f"_ld{ld_}"
+    rec = {"n": cfg["N"], "rods": cfg["rods_per_gpu"], "operator": cfg["operator"], "ld": ld_,
            "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
            "rocprofv3_kernel_avg_ns": summary.get("avg_ns"), "rocprofv3_kernel_calls": summary.get("calls"),
            "date": datetime.date.today().isoformat(),
            "lib_sources_sha16": line["roofline"].get("lib_sources_sha16"),   # bench.py replays this record only for the same sources
            "source": f"profiles/{tag}_rocprofv3_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"}
-    json.dump(rec, open(os.path.join(prof, f"hbm_traffic_n{cfg['N']}_r{cfg['rods_per_gpu']}_{cfg['operator']}.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(prof, f"hbm_traffic_n{cfg['N']}_r{cfg['rods_per_gpu']}_{cfg['operator']}{ld_tag}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(prof, f"{tag}_rocprofv3_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
