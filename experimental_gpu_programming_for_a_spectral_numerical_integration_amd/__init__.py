@@ -110,7 +110,7 @@ def build_library(force: bool = False) -> str:
     import subprocess
 
     csrc = os.path.join(_PKG, "csrc")
-    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    cmd = ["make", "-j4", "-C", csrc] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
     return library_path()
 

@@ -1,0 +1,1651 @@
+#ifndef SRI_APPLY_KERNEL_H
+#define SRI_APPLY_KERNEL_H
+// sri_apply_kernel.h — the hot path's KERNEL (included by the per-geometry translation units sri_apply_<geometry>.hip, which
+// instantiate its variants, and by sri_apply.hip, which owns the handle and the C ABI): Y[R x M] = A[R x R] * X[R x M] in fp64 on gfx950 (MI355X).
+//
+// Replaces the dense products of the reference:
+//   main.cpp:172   r_stack = Dn_NN_inv * (b_NN - ivp)          (A = Dn_NN^-1, integration)
+//   main.cpp:97    (I_s (x) Dn) * chi  ==  vec(Dn * X)          (A = D_N, differentiation)
+// batched over rods: X holds one column per (rod, state component), column-major, so a column
+// is R contiguous doubles (main.cpp:113,130-133).
+//
+// Design (DESIGN.md §4 has the measurements behind every choice):
+//   * v_mfma_f64_16x16x4_f64 does all the arithmetic.  Measured on MI355X (profiles/
+//     r01_mfma_f64_probe.log): one issue per 64 cycles per SIMD, same dependent latency,
+//     77.5 TF chip-wide; f64 VALU work shares that pipe, so the inner loop holds no f64 VALU.
+//   * A (up to 8 MiB at N=1024) does not fit a CU.  It is packed on the host ONCE, at handle
+//     creation, into the exact byte order the MFMA fragments are read in
+//     ([row block][k chunk][16-row tile][k pair][lane][2]), so that a K-slab is one linear
+//     LDS-DMA copy (global_load_lds_dwordx4, no VGPRs) and every fragment read is a
+//     conflict-free 1-KiB ds_read_b128.  A stays resident in each XCD's 4 MiB L2; HBM sees it once.
+//   * The X panel is streamed from HBM exactly once, also by LDS-DMA: every wave instruction
+//     moves 8 columns x 128 contiguous bytes.  The LDS image keeps one 128-byte row per column
+//     with its eight 16-byte pieces XOR-swizzled by (column>>1)&7 — applied on the per-lane
+//     SOURCE address, because the LDS side of an LDS-DMA is lane-linear — which makes the
+//     X-fragment ds_read_b128 conflict-free (tools/lds_bank_model.py; SQ_LDS_BANK_CONFLICT = 0).
+//   * The X fragment is the MFMA's first operand, i.e. every tile is accumulated TRANSPOSED: the 16
+//     lanes of a quarter-wave hold 16 rows of one column, and interleaving the rows of two stacked
+//     tiles (row_of_slot) gives each lane two adjacent rows, so Y leaves in 16-byte stores that
+//     are 256 contiguous bytes per quarter-wave.  The k order inside a block of 8 is a property of the handle
+//     (sri_apply_summation_order): operators of up to 512 rows — the headline N = 256 among them — and every Dn_NN^-1
+//     take 16-byte X-fragment reads, so one MFMA sums four k of EQUAL PARITY (evens before odds: 0,2,4,6 | 1,3,5,7;
+//     sri_internal.h: k_of_paired); differentiation operators of more than 512 rows sum in the reference's own
+//     ASCENDING order (main.cpp:172) from 8-byte reads (k_of_ascending), because on smooth fields under D_1024 the
+//     paired order is measurably less accurate (see "The k order of a launch" below).  The row permutation and the
+//     k order are folded into the host-side packing of A; X and Y keep the caller's plain column-major layout.
+//   * PERSISTENT: one 512-thread workgroup per CU (256 x 128 tile, 2 waves per SIMD, 144 KiB LDS
+//     ring of 3 stages, 2 in flight) walks tiles b, b+grid, ...; the (tile, k chunk) pairs form one
+//     stream that keeps flowing across tile boundaries.  Stages are awaited with counted
+//     s_waitcnt vmcnt(N) + raw s_barrier (never __syncthreads(), whose fence drains vmcnt), so that
+//     the previous tile's Y stores may stay in flight for two stages.
+//   * The LDS-DMA pieces of a refill are dropped one by one behind MFMA groups (a piece costs the
+//     issuing wave 60-180 cycles), and the two wave groups of a workgroup run the stream SHIFTED
+//     by most of a k pair against the shared barriers: after a barrier the late group still owns
+//     MFMAs with operands in registers, and each group's stores are issued while the other computes.
+//   * Any fp64 panel qualifies: 8-byte alignment is enough for LDS-DMA and 16-byte stores
+//     (tools/unaligned_probe.hip); rows % 16 != 0 (every integration operator: N-1 rows) is handled by
+//     safe source addresses + an LDS fix-up of the last k chunk (template parameter TAIL).
+//   * The initial-value term of sri_integrate (Y -= w x_base^T, main.cpp:162-164) costs nothing when rows % 16 != 0:
+//     -w is packed as operator column k = rows, x_base rides in the matching slot of the X image (FOLD).
+//   * EPI_QUAT turns the store stage into the caller on the far side of the product: the next right-hand side
+//     1/2 A(K) Q of the quaternion fixed point is formed from the accumulators (sri_rod.hip drives it).
+//
+// There is no CPU fallback: without a gfx950 device every entry point fails with an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#define SRI_DEVICE_HELPERS 1
+#include "sri_internal.h"
+
+namespace sri {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+
+#define SRI_HIP(call)                                            \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) {                                     \
+      ::sri::record_hip_error(static_cast<int>(e__));            \
+      (void)hipGetLastError();                                   \
+      return SRI_EHIP;                                           \
+    }                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Tile geometry
+// ---------------------------------------------------------------------------------------------
+constexpr int BK = kChunkK;          // 16 k per stage
+constexpr int KPAIRS = BK / 8;       // 16-byte fragment reads per stage and tile
+constexpr int X_ROW_BYTES = BK * 8;  // one column of the X stage: 128 B = 8 pieces of 16 B
+// The k order of a launch (template parameter ASC of the kernel, fixed per handle; sri_internal.h has the two maps):
+//   paired    (rows <= 512): a lane's 16-byte X read holds two consecutive k, so an MFMA sums four k of equal parity —
+//             fewest LDS instructions (measured 2.4 % faster at N = 256 than ascending);
+//   ascending (rows  > 512): the reference's own order, from 8-byte X reads (one per MFMA).  On smooth fields under
+//             D_1024 the paired order is 1.56e-12 away from the CPU reference (1.33e-12 from a binary128 product), the
+//             ascending order 0.97e-12 (0.55e-12; the CPU reference itself: 0.92e-12) — profiles/r02_parity_report.json.
+// Both orders are reproduced bit for bit by a CPU model in the test tree (a chain of four fused multiply-adds per MFMA).
+// Measured and dropped: ascending order from 16-byte reads + v_permlane16_swap_b32 (two 32-bit VALU moves per fragment
+// exchange the halves between adjacent 16-lane rows): correct, but 2.1 % slower than the 8-byte reads.
+#ifndef SRI_ASCENDING_ABOVE_ROWS
+#define SRI_ASCENDING_ABOVE_ROWS 512   // A/B knob (tools/ab_apply.py): 0 = ascending wherever the variant exists, 1 << 30 = never
+#endif
+constexpr uint32_t kAscendingAboveRows = SRI_ASCENDING_ABOVE_ROWS;
+inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_ascending(j, g, e) : k_of_paired(j, g, e); }
+#ifndef SRI_SCHED_HINTS
+#define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
+#endif
+// A/B knobs of the tile end (tools/ab_apply.py; every combination gives bit-identical results):
+#ifndef SRI_TAIL_ABL
+#define SRI_TAIL_ABL 0               // timing-only ablations of the odd-row-count variants (tools/ab_tail.sh; results are WRONG when non-zero):
+#endif                               //   1 = no LDS write in tail_fix_fast, 2 = tail stages wait like any other, 4 = plain stores on half-empty waves,
+                                     //   8 = every operator takes the TAIL instantiation (with 2: results stay right when rows % 16 == 0)
+#ifndef SRI_STORE_SADDR
+#define SRI_STORE_SADDR 1            // 1: full tiles store through `global_store_dwordx4 v_off, v[..], s[base:base+1] offset:imm` —
+#endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
+
+// WM x WN waves, each owning TM x TN MFMA tiles of 16x16; NSTAGE LDS ring slots.
+// STRIP_ = 1: one more 16-row tile of the operator per row block, below the BM rows the waves own (A_ROWS = BM + 16): a
+// 16 x BN strip of the output that the waves share, 16 columns each — the last 1-16 rows of an operator of 256 a + r rows
+// ride along with the last 256-row block, on the X stages that are in LDS anyway (round 4, "Parts").
+template <int WM_, int WN_, int TM_, int TN_, int NSTAGE_, int STRIP_ = 0>
+struct Geo {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NSTAGE = NSTAGE_, STRIP = STRIP_;
+  static constexpr int NW = WM * WN;
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int WAVES_PER_SIMD = (NW + 3) / 4 < 2 ? 2 : (NW + 3) / 4;   // launch-bounds hint
+  static constexpr int BM = WM * TM * 16;
+  static constexpr int BN = WN * TN * 16;
+  static constexpr int A_ROWS = BM + 16 * STRIP;
+  static constexpr int A_BYTES = A_ROWS * BK * 8;
+  static constexpr int A_STRIP_OFFSET = BM * BK * 8;                    // the strip's tile inside a stage's operator slab
+  static constexpr int A_PIECES = A_BYTES / 1024;
+  static constexpr int X_BYTES = BN * BK * 8;
+  static constexpr int STAGE_BYTES = A_BYTES + X_BYTES;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int A_DMA_PER_WAVE = (A_PIECES + NW - 1) / NW;         // (a slab that does not split evenly: the last pieces are fetched twice)
+  static constexpr int X_DMA_PER_WAVE = X_BYTES / 1024 / NW;
+  static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
+  static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
+  static constexpr int NSTORE = TM * TN * 2 + 4 * STRIP;                // Y store instructions per wave of a full tile (the strip: four of 8 bytes)
+  // EPI_QUAT: the strain coefficients of a tile's rods (BN/4 rods x 9 doubles, contiguous in memory) travel with the
+  // tile's first stage into a side buffer behind the ring; QE_BUFS tiles may be between "issued" and "epilogue read".
+  // Each buffer also holds the Legendre factor P1 of the tile's BM rows.  Two buffers are enough when a tile has
+  // >= 3 k chunks, one-chunk tiles need four (see issue_qe); the count is a launch parameter.
+  static constexpr int QE_BYTES = (BN / 4 * 72 + 255) / 256 * 256;      // whole 256-byte wave pieces
+  static constexpr int P1_BYTES = BM * 8;
+  static constexpr int TIPS_BYTES = BN * 8;                             // previous tip value of every column (convergence monitor)
+  static constexpr int SIDE_BYTES = QE_BYTES + P1_BYTES + TIPS_BYTES;
+  static constexpr int lds_bytes_quat(int bufs) { return LDS_BYTES + bufs * SIDE_BYTES; }
+  // FOLD on the LDS-DMA path (sri_integrate of an operator with rows % 16 != 0): the x_base value of each of the tile's
+  // columns travels with the tile's first stage into a small buffer at the very end of the LDS allocation — 256 bytes per
+  // wave (the columns of that wave's own X pieces), two tiles in flight.
+  static constexpr int XB_WAVE_BYTES = 8 * X_DMA_PER_WAVE * 8 > 256 ? 8 * X_DMA_PER_WAVE * 8 : 256;
+  static constexpr int XB_BYTES = 2 * NW * XB_WAVE_BYTES;
+  static_assert(8 * X_DMA_PER_WAVE * 8 <= XB_WAVE_BYTES, "one 8-byte entry per column of the wave's X pieces");
+  // the fused quaternion epilogue's side buffers: only geometries that satisfy this may be instantiated with EPI_QUAT
+  static constexpr bool QUAT_OK = STRIP == 0 && LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
+                                  (P1_BYTES + 1023) / 1024 + 1 <= NW;   // P1 slab and previous tips: at most one 1-KiB DMA piece per wave
+  static_assert(A_BYTES % 1024 == 0 && (STRIP != 0 || A_BYTES % (1024 * NW) == 0) && X_BYTES % (1024 * NW) == 0,
+                "stage must split into whole 1-KiB DMA pieces per wave");
+  static_assert(STRIP == 0 || (WM == TN && TM % 2 == 0), "the strip's BN columns are dealt 16 per wave: wave (wm, wn) takes column tile wm of its own 16 TN");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
+  static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
+  static_assert((AHEAD - 1) * DMA_PER_WAVE + NSTORE <= 63, "counted vmcnt must fit the 6-bit counter");
+};
+
+struct ApplyArgs {
+  const double* apack;   // [row_blocks][nk][BM*BK] packed fragments
+  const double* x;
+  double* y;
+  const double* w;       // optional rank-1 epilogue: y -= w[row] * xb[col]   (w padded to row_blocks*BM)
+  const double* xb;
+  double* tips;          // optional: tips[col] = Y[0][col], the rod-tip node (chebyshev_differentiation.h:26: x_0 = L)
+  const double* qe;      // EPI_QUAT only: strain coefficients, 9 per rod (main.cpp:17, 187-195); m/4 rods
+  const double* leg1;    // EPI_QUAT only: P1 of utilities.h:54-59 (= 2X - 1) at the node of every (padded) row
+  uint32_t side_bufs;    // EPI_QUAT only: side buffers behind the ring (2 or 4)
+  const double* tips_prev;   // EPI_QUAT, optional: tip values of the previous iterate, and
+  double* partial;           //   partial[block * WN + wn] = this wave column's largest |tip - previous tip| (NaN if any)
+  const unsigned long long* stop;   // optional: the launch does nothing if *stop != 0 (device-driven fixed-point loops)
+  // optional loop control IN the launch (device-driven fixed-point loops without a control kernel): before anything else every
+  // workgroup folds the `fold_n` partial maxima the PREVIOUS launch left in `fold` into one value u; if u <= fold_tol the
+  // loop has converged (state[0] = 1), else if `iteration` (= completed iterations) >= fold_max_iter the budget is spent
+  // (state[0] = 2); workgroup 0 records {stop, iteration, bits(u)} in `state` and the whole grid returns.
+  const double* fold;
+  uint32_t fold_n;
+  uint32_t iteration;
+  double fold_tol;
+  unsigned long long fold_max_iter;
+  unsigned long long* state;
+  size_t ldx, ldy, m;    // m = number of columns
+  uint32_t rows;         // valid k (= rows of the whole operator)
+  uint32_t rows_out;     // valid output rows of THIS launch: the operator's rows, or the rows of one part of it (y, w, leg1 point at the part's first row)
+  uint32_t nk;           // k chunks
+  uint32_t row_blocks;
+  uint32_t col_tiles;    // tiles = row_blocks * col_tiles, row block slowest (tile = rb * col_tiles + ct)
+  // sri_apply_many: `panels` > 0 independent panels of m columns each behind DEVICE arrays of device pointers (x, y unused);
+  // tile = (panel * row_blocks + rb) * col_tiles + ct.  Plain apply only.
+  const double* const* xs;
+  double* const* ys;
+  uint32_t panels;
+  uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel), set by launch()
+  uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
+  uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
+  unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
+};
+
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// The same with the address split as the instruction takes it: a wave-uniform 64-bit base (SGPR pair) plus a per-lane
+// 32-bit byte offset (one VGPR) — `global_load_lds_dwordx4 v_off, s[base:base+1]`.  All per-stage address arithmetic of
+// the stage stream is then scalar: none of it competes with the MFMAs for the vector ALU (a 64-bit VALU add per piece
+// and the column multiplies of the tile change did: 36-49 VALU instructions per wave and stage).  The empty asm keeps
+// hipcc from folding base + offset back into one loop-invariant 64-bit VGPR pointer.
+// (By reference: the asm "rewrites" the caller's own register, so no copy is made per piece.)
+__device__ __forceinline__ void lds_dma16_sv(const char* uniform_base, uint32_t& lane_offset, void* lds_dst) {
+  asm volatile("" : "+v"(lane_offset));
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_base + lane_offset),
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// (A non-temporal / sc0 cache policy on the X-panel pieces — read once, so that they would not evict the operator from
+// L2 — was measured at N = 1024, where the operator is re-streamed 2.6 x: 0.4-0.8 % slower; N = 256: no change.)
+
+// Y is written once and never read by the kernel: non-temporal stores keep it from lingering in L2, where it would be
+// flushed again at the end of the kernel.  Measured (tools/ab_apply.py, profiles/r02_ab_nt_stores.log): N = 64: 9.4 -> 8.0 us
+// at 8 192 rods, 200.7 -> 197.3 us at 262 144; N = 128: -7 %; N = 256 / 1024: -0.1 %.  Only for panels whose columns start
+// on 128-byte lines (ApplyArgs::nt_stores, set by run()): on a 255-row panel with leading dimension 255 a quarter-wave's
+// 256 bytes straddle three lines and written-through partial lines cost 3 % instead (0.544 vs 0.527 ms at N = 256).
+#ifndef SRI_NT_STORES
+#define SRI_NT_STORES 1
+#endif
+template <bool NT>
+__device__ __forceinline__ void store_y(d2* p, d2 v) {
+  if constexpr (NT && SRI_NT_STORES != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// Full-tile stores with the address split as the instruction takes it — wave-uniform 64-bit base (SGPR pair), constant
+// per-lane 32-bit byte offset (one VGPR for the whole kernel), 13-bit immediate for the row pair: the column step is
+// scalar arithmetic and nothing of a store's address is computed on the vector ALU (the C++ form costs three 64-bit
+// VALU adds per column pair, and hipcc guards every store of a tile whose row count it cannot see with an exec-mask
+// branch).  Inline asm because hipcc folds base + offset back into a 64-bit VGPR pointer.  The stores are not known
+// to the compiler's s_waitcnt insertion — neither are the LDS-DMA pieces' consumers: the kernel counts vmcnt itself.
+// Nor to its hazard recognizer: on gfx940+ a store of more than 8 bytes needs TWO wait states before a vector-ALU write of
+// its data registers (the next pack2 reuses them) — hence the s_nop 1 inside the statement (with one wait state the
+// 64-row kernel produced run-to-run different results).
+template <bool NT, int IMM>
+__device__ __forceinline__ void store16_sv(char* uniform_base, uint32_t lane_offset, d2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (NT && SRI_NT_STORES != 0)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+  else
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void store8_sv(char* uniform_base, uint32_t lane_offset, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(lane_offset), "v"(v), "s"(uniform_base), "n"(IMM) : "memory");
+#endif
+}
+
+// The two doubles of a 16-byte Y store come from two different accumulators and have to be copied side by side:
+// two 64-bit moves instead of the four 32-bit ones hipcc emits for the tuple (every VALU instruction costs MFMA time).
+__device__ __forceinline__ d2 pack2(double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double a, b;
+  asm("v_mov_b64 %0, %1" : "=v"(a) : "v"(lo));
+  asm("v_mov_b64 %0, %1" : "=v"(b) : "v"(hi));
+  return d2{a, b};
+#else
+  return d2{lo, hi};
+#endif
+}
+
+// The value the lane ABOVE holds, inside each row of 16 lanes (a quarter-wave = the 16 row pairs of one column): lane c gets
+// `hi` of lane c - 1, lane 0 gets `wrap` of lane 15.  Two DPP moves per 32-bit half, no LDS, no exec games.
+// Used by the Y stores of a wave whose last row does not exist (255, 1023, 63 ... rows): see store_tile.
+__device__ __forceinline__ double row_above(double wrap, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long long w = __builtin_bit_cast(long long, wrap), h = __builtin_bit_cast(long long, hi);
+  int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(w), 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(lo, static_cast<int>(h), 0x111 /* row_shr:1: lane 0 keeps `old` */, 0xf, 0xf, false);
+  int up = __builtin_amdgcn_update_dpp(0, static_cast<int>(w >> 32), 0x121, 0xf, 0xf, false);
+  up = __builtin_amdgcn_update_dpp(up, static_cast<int>(h >> 32), 0x111, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (static_cast<long long>(up) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
+#else
+  return wrap + hi;
+#endif
+}
+
+// Diagnostic builds: keep a register value opaque/live without emitting an instruction.  (The "v"
+// constraint only exists for the device pass; the host pass parses kernel bodies too.)
+template <class T>
+__device__ __forceinline__ void keep_live(T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+}
+
+// The kernel's argument block, read again from the kernarg segment through a pointer the compiler cannot see through:
+// the loads are emitted where the values are used (scalar loads, only of the fields that are used there) instead of once
+// at kernel entry.  The tile-boundary code (first stage of a tile, Y stores, tail fix-up) takes its ~25 argument words
+// this way: kept resident they pushed the stage loop past the 102 scalar registers of a wave, and every spilled word
+// is a v_readlane / v_writelane — vector-ALU instructions, i.e. MFMA time — in the middle of the MFMA stream.
+#ifndef SRI_RELOAD_ARGS
+#define SRI_RELOAD_ARGS 1            // A/B knob: 0 = keep the argument block resident in scalar registers (spills into the MFMA stream)
+#endif
+#if SRI_RELOAD_ARGS
+#define SRI_ARGS_HERE reload_kernel_args<ApplyArgs>()
+#else
+#define SRI_ARGS_HERE p
+#endif
+struct ApplyArgs;
+template <class Args>
+__device__ __forceinline__ Args reload_kernel_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __attribute__((address_space(4))) Args* base = (const __attribute__((address_space(4))) Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(base));
+  return *base;
+#else
+  return Args{};
+#endif
+}
+
+// One pointer out of a device array of pointers, by a SCALAR load (the index is wave-uniform): a vector load here would be
+// one more vmcnt event in a kernel that counts vmcnt itself — and a reason for hipcc to insert waits of its own.
+template <class T>
+__device__ __forceinline__ T* load_uniform_pointer(T* const* array, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  T* const* slot = array + index;
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(slot) : "memory");
+  return reinterpret_cast<T*>(v);
+#else
+  return array[index];
+#endif
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ... — for values that must reach an instruction as immediates.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Wait until all but the YOUNGER youngest vector-memory operations of this wave have completed
+// (vmcnt counts loads, LDS-DMA and stores together, in issue order) and its LDS writes are done,
+// then rendezvous.  __syncthreads() is not used in the kernel: its fence always drains vmcnt to 0,
+// which would also wait for the newest stages in flight and for the previous tile's Y stores.
+template <int YOUNGER>
+__device__ __forceinline__ void wait_stage_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNGER) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel: PERSISTENT.  gridDim.x workgroups (<= resident capacity of the chip) each walk
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The (tile, k chunk) pairs of a workgroup form ONE
+// stream of stages pushed through an NSTAGE-slot LDS ring with NSTAGE-1 stages in flight: the ring
+// keeps streaming across tile boundaries, and the Y stores of a finished tile drain behind the
+// next tile's MFMAs (the first AHEAD waits of a tile allow them to stay outstanding).
+//   DMA   : X by LDS-DMA (needs 16-byte aligned columns and rows % 16 == 0), Y by 16-byte stores.
+//           Otherwise X goes through registers with bounds checks and zero fill, Y by guarded
+//           8-byte stores: any rows / ld / M / alignment.
+//   RANK1 : epilogue subtracts w[row]*xb[col] (the initial-value term of main.cpp:162-164,172).
+//   TAIL  : rows % 16 != 0 (DMA builds): safe source addresses + LDS fix-up for the last k chunk of a tile.
+//   LEAN  : a TAIL build WITHOUT the safe source addresses of the panel's last column (its last chunk is fetched where it lies,
+//           up to 16 - rows % 16 elements past the column's end, like every other column's): launched only where run() has
+//           checked that those bytes share their 4-KiB page with the panel's last valid byte — see run().
+//   STAMP : diagnostic only — lane 0 of each workgroup records shader-clock / real-time stamps.
+//   ABL   : diagnostic only (tools/apply_diag.hip) — ablation mask, results are WRONG when non-zero:
+//           1 = fetch A only for the first stage, 2 = fetch X only for the first stage,
+//           4 = no Y stores, 8 = read LDS fragments only in the first stage,
+//           16 = (results stay correct) delay workgroup b by (b % 8)/8 of a tile time before it starts,
+//           32 = the early wave group stores nothing, 64 = the late wave group stores nothing,
+//           128 = all tiles store over the first column tile (store issue without HBM write traffic),
+//           256 = accumulators never re-zeroed, 512 = (results stay correct) workgroups of one XCD start (b / 8 % 32) / 32 of a tile apart.
+//   EPI   : EPI_QUAT fuses the caller on the far side of the product into the store stage:
+//           the panel is 4 columns (w, x, y, z) per rod, Q = A X - w xb^T is the new quaternion iterate, and what
+//           is stored is the NEXT right-hand side G = 1/2 A(K) Q of main.cpp:71-84 with K = Phi(X_row) qe
+//           (utilities.h:49-67, main.cpp:69) formed in registers — one Picard iteration of the rod pipeline per
+//           launch, no K or Q panel in HBM.  The MFMA column index of a 16-column tile is permuted
+//           (t -> 4*(t&3) + (t>>2), applied to the X-fragment read address only) so that the four accumulator
+//           registers of a lane are the four components of ONE rod at one node; stores keep their shape.
+// ---------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_QUAT = 1 };
+
+template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false, bool LEAN = false>
+__global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
+  constexpr bool ASCK = ASC;
+  static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
+  static_assert(EPI == EPI_NONE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
+  // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
+  // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
+  // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
+  // XOR swizzle of the 16-byte pieces of an X-image row by (column >> 1) & SWZ.  ds_read_b128 is served in four 16-lane
+  // groups ({0-3,12-15,20-27}, ...; tools/lds_bank_model.py): with the plain column order & 7 is conflict-free, with the
+  // permuted column order of EPI_QUAT it is 2-way (measured: SQ_LDS_BANK_CONFLICT = 0.5 x the X-read cycles) and & 6 is
+  // conflict-free instead.
+  // With the ascending k order the X fragments are 8-byte reads, served in two 32-lane halves that each cover all 16
+  // columns of the tile in either column order: & 7 is conflict-free for both.
+  constexpr int SWZ = (EPI == EPI_QUAT && !ASCK) ? 6 : 7;
+  constexpr bool FOLD = RANK1 && (TAIL || !DMA);
+  constexpr bool RANK1_EPI = RANK1 && !FOLD;
+  constexpr bool XBUF = FOLD && DMA;                  // x_base rides through the LDS side buffer (Geo::XB_BYTES)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
+  if constexpr (STAMP) {
+    st_t0 = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+
+#ifndef SRI_WG_PHASE
+#define SRI_WG_PHASE 0               // experiment: the second half of the grid (the second workgroup of every CU) starts half a tile later
+#endif
+  if constexpr (SRI_WG_PHASE != 0 && NW == 4) {
+    if (blockIdx.x >= gridDim.x / 2) {
+      const unsigned steps = p.nk * 4096u / 8128u;
+      for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  if constexpr ((ABL & 512) != 0) {
+    // workgroups of ONE XCD (consecutive b / 8) start (b / 8 % 32) / 32 of a tile apart: no two CUs of an XCD end a tile together
+    const unsigned steps = ((blockIdx.x >> 3) % 32) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 32 / 8128;
+    for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  if constexpr ((ABL & 16) != 0) {
+    // one tile = nk stages x 2*TM*TN MFMAs x 64 cycles x waves per SIMD; s_sleep 127 ~ 8128 cycles
+    const unsigned steps = (blockIdx.x % 8) * (p.nk * 2 * TM * TN * 64 * (NW / 4)) / 8 / 8128;
+    for (unsigned i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const int tid = threadIdx.x;
+  if constexpr (EPI == EPI_QUAT) {
+    if (p.stop != nullptr && *p.stop != 0ull) return;          // uniform over the grid: the loop has already converged
+    if (p.state != nullptr && p.fold_n != 0u) {
+      // The loop control that used to be a one-block kernel after every step: the step itself, at its start, folds what the
+      // previous step left.  Every workgroup reads the same few hundred values in the same order, so all of them take the
+      // same decision without talking to each other (same-address atomics from 8 XCDs cost ~200 ns each).  NaN is
+      // "not converged": the loop then runs to its budget.
+      double local = 0.0;
+      for (uint32_t i = tid; i < p.fold_n; i += G::THREADS) {
+        const double d = p.fold[i];
+        local = (d > local || d != d) ? d : local;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double other = __shfl_xor(local, off);
+        local = (other > local || other != other) ? other : local;
+      }
+      double* const wave_max = reinterpret_cast<double*>(smem);               // nothing is in flight yet: the ring is free
+      if ((tid & 63) == 0) wave_max[tid >> 6] = local;
+      __syncthreads();
+      local = wave_max[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) local = (wave_max[w] > local || wave_max[w] != wave_max[w]) ? wave_max[w] : local;
+      __syncthreads();                                                        // the ring may be written from here on
+      const unsigned long long verdict = local <= p.fold_tol ? 1ull : (p.iteration >= p.fold_max_iter ? 2ull : 0ull);
+      if (blockIdx.x == 0 && tid == 0) {
+        p.state[1] = p.iteration;
+        p.state[2] = static_cast<unsigned long long>(__double_as_longlong(local));
+        if (verdict != 0ull) p.state[0] = verdict;
+      }
+      if (verdict != 0ull) return;
+    }
+  }
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef SRI_WAVE_ROW_MAJOR
+#define SRI_WAVE_ROW_MAJOR 0         // A/B knob: 1 = a wave group (waves 0..NW/2-1 / the rest) owns ALL rows of half the tile's columns
+#endif
+  const int wm = SRI_WAVE_ROW_MAJOR ? wid % G::WM : wid / WN, wn = SRI_WAVE_ROW_MAJOR ? wid / G::WM : wid % WN;
+  const int c = lane & 15, g = lane >> 4;
+
+  // Which tiles this workgroup walks: first_tile, first_tile + tile_step, ... (my_tiles of them; tile = rb * col_tiles + ct).
+  //   order 0: b, b + grid, ...  With the row block slowest, all CUs stream the same slab of the operator at any time (it
+  //            stays in every XCD's L2) — and an operator of several row blocks re-reads the X panel once per row block.
+  //   order 1 (operators of >= 2 row blocks on a full grid; launch() checks the divisibility): the 32 workgroups of an XCD
+  //            (b % 8 = XCD, round-robin dispatch) are grid/8/RB column tiles x ALL RB row blocks, and a workgroup keeps
+  //            its row block: the RB workgroups that share a column tile run on ONE XCD, in step, so its L2 misses the
+  //            X tile once instead of RB times (the operator's RB slabs stream through that L2 instead, each shared by the
+  //            XCD's column tiles).  N = 1024: HBM traffic 2.6 x algorithmic -> see DESIGN.md §4.
+  uint32_t first_tile = blockIdx.x, tile_step = gridDim.x, my_tiles;      // host guarantees gridDim.x <= tiles
+  if (p.tile_order == 1u) {
+    const uint32_t rbs = p.row_blocks, cpx = (gridDim.x >> 3) / rbs;      // column tiles of an XCD per round
+    const uint32_t slot = blockIdx.x >> 3, ct0 = (blockIdx.x & 7u) * cpx + slot / rbs;
+    tile_step = 8u * cpx;
+    first_tile = (slot % rbs) * p.col_tiles + ct0;
+    my_tiles = (p.col_tiles - ct0 + tile_step - 1) / tile_step;           // launch(): col_tiles >= tile_step, so >= 1
+  } else {
+    my_tiles = ((p.panels != 0 ? p.panels : 1u) * p.row_blocks * p.col_tiles - first_tile + gridDim.x - 1) / gridDim.x;
+  }
+  const uint32_t total_stages = my_tiles * p.nk;
+
+  // ---- issue-side cursor: the (tile, chunk) whose stage is fetched next ------------------------
+  // DMA: instruction i (= wid + it*NW) covers columns 8i..8i+7 of the tile; this lane writes
+  // piece position (lane & 7) of column 8i + (lane >> 3), which must hold source piece
+  // (lane & 7) ^ sigma(column).
+  // Addresses of the LDS-DMA pieces: wave-uniform bases (scalar registers, advanced per stage and per tile by the scalar
+  // ALU) + per-lane 32-bit offsets that only change at the panel's last column tile (clamp).  The host guarantees that
+  // a tile's column span fits 32 bits (BN * ldx * 8 < 2^32).
+  uint32_t xoff[DMA ? G::X_DMA_PER_WAVE : 1];
+  int xsafe[(DMA && TAIL) ? G::X_DMA_PER_WAVE : 1];   // tail chunk only: bytes to step back to a piece that is surely in bounds, or 0
+  bool edge_i = false;                                // TAIL: the tile under the issue cursor holds the panel's LAST column
+  bool tail_base0 = false;                            // TAIL: the chunk offset of the stage under the cursor sits in xoff[] (see cursor_advance)
+  const char* xbase = nullptr;                       // p.x + first column of the tile (uniform)
+  const char* abase = nullptr;                       // operator slab of the tile's row block (uniform)
+  uint32_t aoff = static_cast<uint32_t>(lane) * 16u;
+  uint32_t tile_i = first_tile, kc_i = 0, slot_i = 0, issued = 0;
+  uint32_t tseq_i = 0;       // EPI_QUAT: how many tiles the issue cursor has left behind (selects the qe side buffer)
+  uint32_t tseq_c = 0;       // ... and how many tiles this wave has finished (side buffer of the one in the accumulators)
+  double tip_update = 0.0;   // EPI_QUAT monitor: largest |tip - previous tip| this lane has seen over all its tiles
+  size_t col0_i = 0;
+  auto issue_setup = [&]() __attribute__((always_inline)) {
+    const ApplyArgs q = SRI_ARGS_HERE;
+    // Once per tile.  Everything below hangs on the opaque copy of the tile index, so that hipcc cannot hoist the
+    // division and the multiplies out of the branch and run them in every stage (it did: if-conversion).
+    uint32_t tile_o = tile_i;
+    asm volatile("" : "+s"(tile_o) : : "memory");
+    uint32_t rb = tile_o / q.col_tiles;
+    col0_i = static_cast<size_t>(tile_o % q.col_tiles) * G::BN;
+    const double* xp = q.x;
+    if (q.panels != 0) {                  // sri_apply_many: (panel, row block) = rb / RB, rb % RB
+      xp = load_uniform_pointer(q.xs, rb / q.row_blocks);
+      rb = rb % q.row_blocks;
+    }
+    abase = reinterpret_cast<const char*>(q.apack) + static_cast<size_t>(rb) * q.nk * G::A_BYTES;
+    if constexpr (DMA) {
+      xbase = reinterpret_cast<const char*>(xp + col0_i * q.ldx);
+      const uint32_t ldx_bytes = static_cast<uint32_t>(q.ldx * sizeof(double));
+      const size_t last_col = q.m - 1;
+      const size_t left = last_col - col0_i;                      // columns of the panel behind the tile's first one
+      const uint32_t lim = left < static_cast<size_t>(G::BN) ? static_cast<uint32_t>(left) : static_cast<uint32_t>(G::BN);
+      edge_i = !LEAN && left < static_cast<size_t>(G::BN);
+      tail_base0 = false;
+#pragma unroll
+      for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
+        const uint32_t cc = static_cast<uint32_t>((wid + it * NW) * 8 + (lane >> 3));
+        const uint32_t piece = static_cast<uint32_t>(lane & 7) ^ ((cc >> 1) & SWZ);
+        const uint32_t ccl = cc < lim ? cc : lim;                 // clamp: tail columns re-read a valid one
+        xoff[it] = ccl * ldx_bytes + piece * 16u;
+        // In the last k chunk of a panel whose row count is not a multiple of 16, a piece that holds a k
+        // beyond the last row reaches into the next column — or, for the panel's last column, past the end of the
+        // buffer: THAT one is fetched from the same piece of the PREVIOUS chunk instead (a full chunk of the same
+        // column: rows >= 17 here) and its LDS image is rewritten by fixup_tail() before use.
+        // Only the LAST column of the panel needs that: behind every other column lies the next one (or the padding of a
+        // strided panel), so the piece can be fetched where it is — its valid element arrives by DMA like any other and
+        // fixup_tail() only overwrites the foreign one.
+        if constexpr (TAIL) xsafe[it] = (!LEAN && cc >= lim && 2 * static_cast<int>(piece) + 1 >= static_cast<int>(q.tail_k)) ? X_ROW_BYTES : 0;
+      }
+    }
+  };
+
+  // Register staging for the generic path: the X stage is BN*BK doubles, THREADS*XR of them.
+  constexpr int XR = G::BN * BK / G::THREADS;
+  double xreg[DMA ? 1 : XR];
+
+  bool abl_first = true;   // ablation builds only
+  // EPI_QUAT, first stage of a tile: the 72 bytes of strain coefficients of each of the tile's BN/4 rods and the
+  // Legendre factor P1 of its BM rows, by LDS-DMA into side buffer (tile sequence % side_bufs).  Issued BEFORE the
+  // stage's own pieces: vmcnt retires in order, so the wait for stage (tile, 0) — which every wave passes, followed
+  // by a barrier, before the tile's epilogue — covers them.  Reuse: the pieces of tile j are issued in the body of
+  // stage (j, 0) - 2, after that stage's barrier; the late wave group reads the buffer of tile i in the body of stage
+  // (i+1, 0), before barrier (i+1, 1).  With nk >= 3 chunks per tile, (j, 0) - 2 >= (j-1, 1): two buffers suffice;
+  // with nk = 2 three, with nk = 1 (issue of tile j and epilogue of tile j-3 share a body) four.
+  auto issue_qe = [&]() __attribute__((always_inline)) {
+    if constexpr (EPI == EPI_QUAT) {
+      if (kc_i == 0) {
+        const ApplyArgs q = SRI_ARGS_HERE;
+        // 4-byte pieces (256 B per wave instruction): the caller's array ends exactly after the last rod, and a
+        // 4-byte granule can be clamped at that end without shifting valid data.
+        const size_t total = (q.m >> 2) * 72;                          // >= 72: at least one rod
+        const size_t base = (col0_i >> 2) * 72;
+        char* buf = smem + G::LDS_BYTES + (tseq_i % q.side_bufs) * G::SIDE_BYTES;
+#pragma unroll
+        for (int i = 0; i < (G::QE_BYTES / 256 + NW - 1) / NW; ++i) {
+          const int chunk = wid + i * NW;                              // wave-uniform
+          if (chunk * 256 < G::QE_BYTES) {
+            size_t src = base + chunk * 256 + lane * 4;
+            src = src + 4 <= total ? src : total - 4;                  // ragged last tile: re-read valid bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(q.qe) + src),
+                                             (__attribute__((address_space(3))) void*)(buf + chunk * 256), 4, 0, 0);
+          }
+        }
+        // P1 of the tile's row block: the table is padded to whole row blocks and 16-byte aligned; the last waves
+        // take it (the first ones carry the extra coefficient piece)
+        const int pw = NW - 1 - wid;                                   // wave-uniform
+        if (pw * 1024 < G::P1_BYTES && pw * 1024 + lane * 16 < G::P1_BYTES) {
+          const uint32_t rb = tile_i / q.col_tiles;
+          lds_dma16(reinterpret_cast<const char*>(q.leg1 + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
+                    buf + G::QE_BYTES + pw * 1024);
+        }
+        // previous tip values of the tile's columns (m is a multiple of 4, so 16-byte granules never straddle the end)
+        if (q.tips_prev != nullptr && pw == (G::P1_BYTES + 1023) / 1024 && lane * 16 < G::TIPS_BYTES) {
+          size_t src = col0_i * 8 + lane * 16;
+          src = src + 16 <= q.m * 8 ? src : q.m * 8 - 16;
+          lds_dma16(reinterpret_cast<const char*>(q.tips_prev) + src, buf + G::QE_BYTES + G::P1_BYTES);
+        }
+      }
+    }
+  };
+  // FOLD on the LDS-DMA path, first stage of a tile: x_base of the columns of this wave's own X pieces, 4 bytes per lane
+  // (entry j = lane >> 1 is the column of lane j of tail_fix_fast()), into this wave's corner of the side buffer of tile
+  // sequence parity.  In FRONT of the stage's own pieces, like the coefficient pieces of EPI_QUAT: the counted waits then
+  // at worst wait for it too.  Read back by the SAME wave after its own vmcnt wait for the tile's last stage.
+  char* const xb_side = smem + (EPI == EPI_QUAT ? G::lds_bytes_quat(static_cast<int>(p.side_bufs)) : G::LDS_BYTES);
+  auto issue_xb = [&]() __attribute__((always_inline)) {
+    if constexpr (XBUF) {
+      if (kc_i == 0) {
+        const ApplyArgs q = SRI_ARGS_HERE;
+        const uint32_t j = (static_cast<uint32_t>(lane) >> 1) % (8u * G::X_DMA_PER_WAVE);
+        const size_t col = col0_i + (wid + (j >> 3) * NW) * 8 + (j & 7);
+        const size_t colc = col < q.m ? col : q.m - 1;                       // ragged last tile: any valid address (never read back)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(q.xb) + colc * 8 + (lane & 1) * 4),
+                                         (__attribute__((address_space(3))) void*)(xb_side + (tseq_i & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES),
+                                         4, 0, 0);
+      }
+    }
+  };
+  // Fetch the stage under the cursor into ring slot slot_i; advance the cursor.
+  auto stage_issue = [&]() __attribute__((always_inline)) {
+    issue_qe();
+    issue_xb();
+    char* sA = smem + slot_i * G::STAGE_BYTES;
+    const char* gA = abase + static_cast<size_t>(kc_i) * G::A_BYTES;
+    if (!(ABL & 1) || abl_first) {
+#pragma unroll
+      for (int it = 0; it < G::A_DMA_PER_WAVE; ++it) {
+        int i = wid + it * NW;
+        if constexpr (G::A_PIECES % NW != 0) i = i < G::A_PIECES ? i : G::A_PIECES - 1;   // (fetched twice: same bytes, same place)
+        lds_dma16_sv(gA + i * 1024, aoff, sA + i * 1024);
+      }
+    }
+    if constexpr (DMA) {
+      char* sX = sA + G::A_BYTES;
+      const char* gX = xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES;
+      if (!(ABL & 2) || abl_first) {
+#pragma unroll
+        for (int it = 0; it < G::X_DMA_PER_WAVE; ++it) {
+          const int i = wid + it * NW;
+          if constexpr (TAIL) {
+            lds_dma16_sv(tail_base0 ? xbase : gX, xoff[it], sX + i * 1024);     // see cursor_advance
+          } else {
+            lds_dma16_sv(gX, xoff[it], sX + i * 1024);
+          }
+        }
+      }
+      if constexpr (ABL != 0) abl_first = false;
+    } else {
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const int idx = tid + r * G::THREADS;      // element of the stage, k fastest
+        const int cc = idx / BK, k = idx % BK;
+        const size_t col = col0_i + cc;
+        const uint32_t kk = kc_i * BK + k;
+        xreg[r] = (col < p.m && kk < p.rows) ? p.x[col * p.ldx + kk] : 0.0;
+        if constexpr (FOLD) { if (col < p.m && kk == p.rows) xreg[r] = p.xb[col]; }
+      }
+    }
+  };
+  // One 1-KiB LDS-DMA piece of the stage under the cursor (DMA builds): pieces 0..A_DMA_PER_WAVE-1 move
+  // the operator slab, the rest the X panel.  Lets the main loop drop the pieces between MFMA groups.
+  auto issue_piece = [&](int idx) __attribute__((always_inline)) {
+    char* sA = smem + slot_i * G::STAGE_BYTES;
+    if (idx == 0) { issue_qe(); issue_xb(); }
+    if (idx < G::A_DMA_PER_WAVE) {
+      if (!(ABL & 1) || abl_first) {
+        int i = wid + idx * NW;
+        if constexpr (G::A_PIECES % NW != 0) i = i < G::A_PIECES ? i : G::A_PIECES - 1;
+        lds_dma16_sv(abase + static_cast<size_t>(kc_i) * G::A_BYTES + i * 1024, aoff, sA + i * 1024);
+      }
+    } else {
+      if (!(ABL & 2) || abl_first) {
+        const int it = idx - G::A_DMA_PER_WAVE;
+        const int i = wid + it * NW;
+        if constexpr (DMA && TAIL) {
+          lds_dma16_sv(tail_base0 ? xbase : xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, xoff[it], sA + G::A_BYTES + i * 1024);
+        } else {
+          lds_dma16_sv(xbase + static_cast<size_t>(kc_i) * X_ROW_BYTES, xoff[DMA ? it : 0], sA + G::A_BYTES + i * 1024);
+        }
+      }
+      if constexpr (ABL != 0) { if (idx == G::DMA_PER_WAVE - 1) abl_first = false; }
+    }
+  };
+  // generic path only: registers -> swizzled LDS image of the slot just issued
+  auto stage_commit = [&](uint32_t slot) __attribute__((always_inline)) {
+    if constexpr (!DMA) {
+      char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const int idx = tid + r * G::THREADS;
+        const int cc = idx / BK, k = idx % BK;
+        const int pos = (k >> 1) ^ ((cc >> 1) & SWZ);
+        *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (k & 1) * 8) = xreg[r];
+      }
+    }
+  };
+  auto cursor_advance = [&]() __attribute__((always_inline)) {
+    ++issued;
+    slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
+    if (++kc_i == p.nk) {
+      kc_i = 0;
+      ++tseq_i;
+      tile_i += tile_step;
+      if (issued < total_stages) issue_setup();
+    }
+    if constexpr (DMA && TAIL) {
+      // The last k chunk of the ONE tile that holds the panel's last column: pieces that reach past the end of the buffer
+      // step back one chunk (xsafe).  The chunk's offset moves into the lane offsets so that the step back cannot wrap below
+      // zero (kc_i >= 1 here: rows >= 17); issue_setup() of the next tile rebuilds xoff[].  Every other stage of a TAIL
+      // build issues exactly like a full-chunk one: no vector-ALU work per piece.
+      if (edge_i && kc_i + 1 == p.nk) {
+#pragma unroll
+        for (int it = 0; it < G::X_DMA_PER_WAVE; ++it)
+          xoff[it] = xoff[it] + kc_i * static_cast<uint32_t>(X_ROW_BYTES) - static_cast<uint32_t>(xsafe[it]);
+        tail_base0 = true;
+      }
+    }
+  };
+
+  // ---- accumulators and fragment registers -----------------------------------------------------
+  d4 acc[TM][TN];
+  const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+
+  // constant per-lane byte offset of a full tile's Y stores inside the wave's 64 x 64 block: column g, rows 2c, 2c+1
+  // (the host guarantees that 128 columns of Y span < 4 GiB)
+  uint32_t ylane = static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
+  asm volatile("" : "+v"(ylane));
+  // fragment read addresses (bytes, relative to the slot base)
+  const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
+  // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
+  const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
+  const int sig = ((cs >> 1) & SWZ);
+  const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
+  // Ascending k: one 8-byte X read per MFMA.  Seen as plain loads 2 KiB apart, the reads of two column tiles are paired
+  // by hipcc into ds_read2st64_b64, which runs at half the LDS rate of two ds_read_b64 and, banked mod 32 over 128-byte
+  // rows, with 2-way conflicts (measured: -2 % at N = 256).
+  // Every vector-ALU instruction in the stage loop costs MFMA time, so the per-lane part of a read address is formed
+  // once — xq[j][e] for instruction (j, e): element g & 1 of piece 4j + 2e + (g >> 1) of this lane's column — the slot
+  // base is ONE add per (j, e) and stage, and the column tile is an immediate offset; an empty asm between the reads of
+  // two tiles keeps them apart.
+  int xpp[2] = {0, 0};                                      // paired order: per-lane part of the 16-byte X read of k pair j
+  if constexpr (!ASCK) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xpp[j] = x_off + ((4 * j + g) ^ sig) * 16;
+      asm volatile("" : "+v"(xpp[j]));                       // two registers for the whole kernel, not three VALU instructions per stage
+    }
+  }
+  int xq[ASCK ? 2 : 1][2];
+  if constexpr (ASCK) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) xq[j][e] = x_off + (g & 1) * 8 + ((4 * j + 2 * e + (g >> 1)) ^ sig) * 16;
+  }
+
+  // The strip (G::STRIP): one more accumulator tile per wave — rows BM .. BM + 15 of the row block, columns tile `wm` of the
+  // wave's own TN column tiles — and ONE set of fragments for it, read at the top of a k pair (behind the pair's own
+  // fragments, which are in registers by then) and consumed after the last MFMA group of each k-step: 16 registers in all.
+  d4 sacc = d4{0.0, 0.0, 0.0, 0.0};
+  d2 sfa = d2{0.0, 0.0}, sfb = d2{0.0, 0.0};
+  const int s_a_off = G::A_STRIP_OFFSET + lane * 16;
+  const int s_x_add = wm * 16 * X_ROW_BYTES;                    // from the wave's column tile 0 to its column tile wm
+  // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
+  // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
+  // "groups" (k-step e, row tile tm) of TN MFMAs each.  With PIECES (steady state of the DMA build) one
+  // LDS-DMA piece of the refill is dropped behind each group and pinned there: a piece costs the issuing
+  // wave ~60-180 cycles, a group keeps the pipe busy for TN*64, so the DMA issue disappears in the MFMA
+  // shadow instead of idling the pipe after the barrier.
+  constexpr int GROUPS = 2 * TM;
+  bool abl_read = true;
+  auto read_pair = [&](uint32_t slot, int j, d2 (&a)[TM], d2 (&b)[TN]) __attribute__((always_inline)) {
+    if ((ABL & 8) && !abl_read) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) keep_live(a[tm]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) keep_live(b[tn]);
+      return;
+    }
+    const char* base = smem + slot * G::STAGE_BYTES;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+      a[tm] = *reinterpret_cast<const d2*>(base + a_off + (tm * KPAIRS + j) * 1024);
+    if constexpr (ASCK) {
+      // instruction (j, e) sums k = 8j + 4e + g over the lanes' k slots g: element g & 1 of piece 4j + 2e + (g >> 1)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const char* rd = base + xq[ASCK ? j : 0][e];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          b[tn][e] = *reinterpret_cast<const double*>(rd + tn * 16 * X_ROW_BYTES);
+          asm volatile("" ::: "memory");                         // no ds_read2st64_b64 out of two of these
+        }
+      }
+    } else {
+      const char* rd = base + xpp[j];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        b[tn] = *reinterpret_cast<const d2*>(rd + tn * 16 * X_ROW_BYTES);
+    }
+  };
+  auto strip_read = [&](uint32_t slot, int j) __attribute__((always_inline)) {
+    if constexpr (G::STRIP != 0) {
+      const char* base = smem + slot * G::STAGE_BYTES;
+      sfa = *reinterpret_cast<const d2*>(base + s_a_off + j * 1024);
+      if constexpr (ASCK) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          sfb[e] = *reinterpret_cast<const double*>(base + xq[ASCK ? j : 0][e] + s_x_add);
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        sfb = *reinterpret_cast<const d2*>(base + xpp[j] + s_x_add);
+      }
+    }
+  };
+  // groups [G0, G1) of the k pair held in (a, b); `piece` counts the DMA pieces issued so far in this body
+  auto mfma_groups = [&](const d2 (&a)[TM], const d2 (&b)[TN], auto g0_tag, auto g1_tag, int& piece, auto pieces_tag)
+                         __attribute__((always_inline)) {
+    constexpr int G0 = decltype(g0_tag)::value, G1 = decltype(g1_tag)::value;
+    constexpr bool PIECES = decltype(pieces_tag)::value;
+#pragma unroll
+    for (int gi = G0; gi < G1; ++gi) {
+      const int e = gi / TM, tm = gi % TM;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
+      if constexpr (G::STRIP != 0) {
+        if (tm == TM - 1) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sfb[e], sfa[e], sacc, 0, 0, 0);   // k-step e of the strip
+      }
+      if constexpr (PIECES) {
+        if (piece < G::DMA_PER_WAVE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(piece++);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using IG = std::integral_constant<int, GROUPS>;
+
+  // ---- Y stores of a finished tile (registers -> HBM, no LDS, no wait) --------------------------
+  // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
+  // Optional by-product: the tip-node value of every column (row 0 of the first row block), the "final
+  // integrated state" a multi-GPU run reassembles.  Row 0 sits in acc[0][tn][r] of the lanes with c == 0.
+  auto emit_tips = [&](const ApplyArgs& q, uint32_t rb, size_t col_base) __attribute__((always_inline)) {
+    if (q.tips == nullptr || rb != 0 || wm != 0) return;      // wave-uniform
+    if (c != 0) return;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t col = col_base + tn * 16 + r * 4;
+        if (col < q.m) {
+          double v = acc[0][tn][r];
+          if constexpr (RANK1_EPI) v -= q.w[0] * q.xb[col];
+          q.tips[col] = v;
+        }
+      }
+  };
+  // EPI_QUAT: acc[tm][tn][r] = (A X)[row_base + 32*(tm>>1) + (tm&1)][col_base4 + 16*tn + r], r = w, x, y, z of the rod
+  // in columns col_base4 + 16*tn .. +3.  Same store count and shape as the plain epilogue (the counted waits rely on it).
+  // Operation order of K and G is that of strain_kernel / quat_rhs_kernel (sri_rod.hip), so the fused iteration is
+  // bit-identical to the unfused one.
+  auto store_tile_quat = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    const ApplyArgs q = SRI_ARGS_HERE;
+    const uint32_t rb_c = tile / q.col_tiles;
+    const size_t col0_c = static_cast<size_t>(tile % q.col_tiles) * G::BN;
+    const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
+    const size_t col_base4 = col0_c + wn * (TN * 16) + 4 * g;
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows_out;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows_out + 1);
+    const bool tip_lane = q.tips != nullptr && rb_c == 0 && wm == 0 && c == 0;
+    const char* side = smem + G::LDS_BYTES + (tseq_c % q.side_bufs) * G::SIDE_BYTES;
+    const bool monitor = q.partial != nullptr && rb_c == 0 && wm == 0;         // wave-uniform
+    d2 p1[TM / 2];                                               // P1 at this lane's row pairs
+#pragma unroll
+    for (int t = 0; t < TM / 2; ++t)
+      p1[t] = *reinterpret_cast<const d2*>(side + G::QE_BYTES + (wm * (TM * 16) + 2 * c + 32 * t) * 8);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const size_t col = col_base4 + tn * 16;
+      if (!full && col >= q.m) continue;                       // m is a multiple of 4: a rod is in or out as a whole
+      const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
+      double q9[9], xb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q9[i] = qe[i];
+      if constexpr (RANK1_EPI) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xb[r] = q.xb[col + r];
+      }
+#pragma unroll
+      for (int t = 0; t < TM / 2; ++t) {
+        const uint32_t row = row_base + 32 * t;
+        double gq[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double P1 = p1[t][e];
+          const double P2 = ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1);   // as strain_kernel (sri_rod.hip)
+          double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
+          if constexpr (RANK1_EPI) {
+            const double wv = q.w[row + e];
+            qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
+          }
+          if (tip_lane && t == 0 && e == 0) {
+            q.tips[col + 0] = qw; q.tips[col + 1] = qx; q.tips[col + 2] = qy; q.tips[col + 3] = qz;
+            if (monitor) {
+              const double* old = reinterpret_cast<const double*>(side + G::QE_BYTES + G::P1_BYTES) + (wn * TN + tn) * 16 + 4 * g;
+              const double qv[4] = {qw, qx, qy, qz};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const double d = fabs(qv[r] - old[r]);
+                tip_update = (d > tip_update || d != d) ? d : tip_update;       // NaN propagates as "not converged"
+              }
+            }
+          }
+          double hk[3];                                          // K/2: halving is exact
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double s = q9[a * 3 + 0];                             // P0 = 1
+            s = s + P1 * q9[a * 3 + 1];
+            s = s + P2 * q9[a * 3 + 2];
+            hk[a] = 0.5 * s;
+          }
+          quat_rhs_half(hk[0], hk[1], hk[2], qw, qx, qy, qz, gq[e]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double* yp = q.y + (col + r) * q.ldy + row;
+          if (full ? (all_rows || row + 1 < q.rows_out) : (DMA && row + 1 < q.rows_out)) {
+            *reinterpret_cast<d2*>(yp) = d2{gq[0][r], gq[1][r]};
+          } else {
+            if (row < q.rows_out) yp[0] = gq[0][r];
+            if (!full && row + 1 < q.rows_out) yp[1] = gq[1][r];
+          }
+        }
+      }
+    }
+    return full;
+  };
+  // The strip's 16 x 16 tile of this wave: lane (c, g) holds row BM + c of the columns g, g + 4, g + 8, g + 12 of the wave's
+  // column tile wm — four 8-byte stores, 128 contiguous bytes per column.  `counted`: every column exists and the wave is on
+  // the counted-store path: exactly four store INSTRUCTIONS must be issued whatever the number of valid rows (the stage waits
+  // count them), so the rows that do not exist are masked out through exec, not branched around.
+  auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted) __attribute__((always_inline)) {
+    if constexpr (G::STRIP != 0) {
+      const uint32_t row = rb_c * G::BM + G::BM + c;
+      const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + g;
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = sacc[r];
+        if constexpr (RANK1_EPI) {
+          if (row < q.rows_out && col_s + 4 * r < q.m) v[r] -= q.w[row] * q.xb[col_s + 4 * r];
+        }
+      }
+      if (counted) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t valid = q.rows_out - (rb_c * G::BM + G::BM);                    // 1 .. 16 rows of the strip exist
+        const uint32_t m16 = valid >= 16u ? 0xffffu : ((1u << valid) - 1u);
+        const unsigned long long mask = 0x0001000100010001ull * m16;                   // the same 16 row lanes in every quarter-wave
+        const size_t ldy8 = q.ldy * sizeof(double);
+        char* const b0 = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16) + wm * 16) * ldy8 + (static_cast<size_t>(rb_c) * G::BM + G::BM) * sizeof(double);
+        char* const b1 = b0 + 4 * ldy8;
+        char* const b2 = b1 + 4 * ldy8;
+        char* const b3 = b2 + 4 * ldy8;
+        const uint32_t off = static_cast<uint32_t>(g) * static_cast<uint32_t>(ldy8) + static_cast<uint32_t>(c) * 8u;
+        asm volatile("s_mov_b64 exec, %9\n\t"
+                     "global_store_dwordx2 %0, %1, %5\n\t"
+                     "global_store_dwordx2 %0, %2, %6\n\t"
+                     "global_store_dwordx2 %0, %3, %7\n\t"
+                     "global_store_dwordx2 %0, %4, %8\n\t"
+                     "s_mov_b64 exec, -1\n\ts_nop 1"
+                     ::"v"(off), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(mask) : "memory");
+#endif
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row < q.rows_out && col_s + 4 * r < q.m) ypanel[(col_s + 4 * r) * q.ldy + row] = v[r];
+      }
+    }
+  };
+  constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && !RANK1_EPI && (ABL & 128) == 0 && EPI == EPI_NONE;
+  auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
+    const ApplyArgs q = SRI_ARGS_HERE;
+    uint32_t rb_c = tile / q.col_tiles;
+    double* yp_ = q.y;
+    if (q.panels != 0) {                  // sri_apply_many
+      yp_ = load_uniform_pointer(q.ys, rb_c / q.row_blocks);
+      rb_c = rb_c % q.row_blocks;
+    }
+    double* const ypanel = yp_;
+    // ABL & 128: every tile stores over the FIRST column tile (same instructions, no HBM write traffic)
+    const size_t col0_c = (ABL & 128) ? 0 : static_cast<size_t>(tile % q.col_tiles) * G::BN;
+    const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
+    const size_t col_base = col0_c + wn * (TN * 16) + g;
+    // "full": every column of the tile exists and at most the very last row of the row block is missing
+    // (rows = 255, 1023, 63, ...).  Then every wave issues at least NSTORE store instructions, which is
+    // what the counted waits of the stage stream rely on.
+    const bool all_rows = rb_c * G::BM + G::BM <= q.rows_out;
+    const bool full = DMA && (col0_c + G::BN <= q.m) && (rb_c * G::BM + G::BM <= q.rows_out + 1);
+    if ((ABL & 4) != 0 || ((ABL & 32) != 0 && wid < NW / 2) || ((ABL & 64) != 0 && wid >= NW / 2)) {
+      // ablation: keep the accumulators live, store nothing
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
+      return false;
+    } else if (SADDR_STORES && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + (TM / 2 >= 2 ? 1 : 0))) {
+      // Every column of the tile exists and this WAVE's 64 rows do too, except possibly the very last one (255, 1023, ...
+      // rows): NSTORE 16-byte stores, straight-line, no vector-ALU address arithmetic (store16_sv).  Decided per wave —
+      // the counted waits are per wave as well.
+      const bool odd = (SRI_TAIL_ABL & 4) == 0 && rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1;   // wave-uniform: the last row pair is half empty
+      const size_t ldy8 = q.ldy * sizeof(double);
+      char* const ybase = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16)) * ldy8 +
+                          (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
+      auto emit = [&](auto nt_tag, auto odd_tag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(nt_tag)::value, ODD = decltype(odd_tag)::value;
+        char* cb = ybase;                                                         // uniform: stepped by the scalar ALU
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (tn + r != 0) {
+              cb += 4 * ldy8;                                                       // columns g + 4 (tn * 4 + r)
+              asm volatile("" : "+s"(cb));                                          // one running base, not 16 hoisted (and spilled) ones
+            }
+            static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
+              constexpr int t = decltype(tc)::value;
+              if constexpr (ODD && t == TM / 2 - 1) {
+                // The wave's last row pair is half empty (lane 15 holds row rows - 1 and a row that does not exist).  Every
+                // lane stores its pair shifted UP by one row instead: {row 2c - 1 (from the lane above; lane 0: the last row
+                // of the previous pair), row 2c} at its usual address - 8.  Still one 16-byte store per lane, all 64 lanes, 256
+                // contiguous bytes per quarter-wave; the one row written twice (by this store and the previous pair's) gets
+                // the same value.  (Round 3 stored 16 bytes from 15 lanes and 8 from the last under exec masks: 48 store
+                // instructions and ~190 basic blocks on these waves, the slowest of their workgroup at every tile end.)
+                // (geometries with one row pair per wave never come here with a half-empty pair: see the branch condition)
+                const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
+                store16_sv<NT, 256 * t - 8>(cb, ylane, pack2(above, acc[2 * t][tn][r]));
+              } else {
+                store16_sv<NT, 256 * t>(cb, ylane, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
+              }
+            });
+          }
+      };
+      if (q.nt_stores != 0) { if (odd) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
+      else { if (odd) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
+      store_strip(q, rb_c, col0_c, ypanel, true);
+      emit_tips(q, rb_c, col_base);
+      return true;
+    } else if (!SADDR_STORES && full) {                     // (with SADDR_STORES every tile that is `full` took the branch above)
+      // rank-1 term: this lane's TM row factors once per tile, one x_base value per column (not per store)
+      double wv[TM / 2][2];
+      if constexpr (RANK1_EPI) {
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t) {
+          wv[t][0] = q.w[row_base + 32 * t];
+          wv[t][1] = q.w[row_base + 32 * t + 1];   // w is zero padded
+        }
+      }
+      auto emit = [&](auto nt_tag) __attribute__((always_inline)) {
+        constexpr bool NT = decltype(nt_tag)::value;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const size_t col = col_base + tn * 16 + r * 4;
+            double xbv = 0.0;
+            if constexpr (RANK1_EPI) xbv = q.xb[col];
+#pragma unroll
+            for (int t = 0; t < TM / 2; ++t) {
+              const uint32_t row = row_base + 32 * t;
+              double* yp = ypanel + col * q.ldy + row;
+              double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
+              if constexpr (RANK1_EPI) {
+                v0 -= wv[t][0] * xbv;
+                v1 -= wv[t][1] * xbv;
+              }
+              if (all_rows || row + 1 < q.rows_out) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
+              else *yp = v0;                                                                 // the lane holding the last row
+            }
+          }
+      };
+      if (q.nt_stores != 0) emit(std::true_type{}); else emit(std::false_type{});   // same store count either way
+      store_strip(q, rb_c, col0_c, ypanel, true);
+      emit_tips(q, rb_c, col_base);
+      return true;
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t col = col_base + tn * 16 + r * 4;
+          if (col >= q.m) continue;
+          double* ycol = ypanel + col * q.ldy;
+          double xbv = 0.0;
+          if constexpr (RANK1_EPI) xbv = q.xb[col];
+#pragma unroll
+          for (int t = 0; t < TM / 2; ++t) {
+            const uint32_t row = row_base + 32 * t;
+            double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
+            if constexpr (RANK1_EPI) {
+              if (row < q.rows_out) v0 -= q.w[row] * xbv;
+              if (row + 1 < q.rows_out) v1 -= q.w[row + 1] * xbv;
+            }
+            if (DMA && row + 1 < q.rows_out) {
+              *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
+            } else {
+              if (row < q.rows_out) ycol[row] = v0;
+              if (row + 1 < q.rows_out) ycol[row + 1] = v1;
+            }
+          }
+        }
+      store_strip(q, rb_c, col0_c, ypanel, false);
+      emit_tips(q, rb_c, col_base);
+      return false;
+    }
+  };
+
+  // ---- the stage stream ----------------------------------------------------------------------------
+  // Stage s lives in ring slot s % NSTAGE; wait(s) + barrier(s) = "stage s has landed for every wave, and
+  // every wave has finished READING stage s-1", after which the slot of stage s-1 is refilled with stage
+  // s+AHEAD.  The two wave groups of a workgroup run the same stream against the same barriers but
+  // SHIFTED by most of a k pair:
+  //   early (waves 0..NW/2-1):  barrier(s) | pair (s,0) | pair (s,1) | [tile end: Y stores]
+  //   late  (waves NW/2..NW-1): reads (s-1,1), first group | barrier(s) | rest of (s-1,1) | [stores] | pair (s,0)
+  // Right after a barrier the late waves still own MFMAs whose operands are in registers, which covers the
+  // early waves' LDS-read latency; each group's Y stores (limited to ~64 B/clk per CU) are issued while the
+  // other group is in the middle of its MFMAs; and the DMA pieces of both groups sit behind MFMA groups.
+  // LDS hazards are those of the unshifted stream because every read of slot s-1 still precedes barrier(s).
+  constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
+  constexpr int W_BOUNDARY = W_STEADY + G::NSTORE;          // ... plus one full tile's stores
+  static_assert(AHEAD == 1 || AHEAD == 2, "the wait counts assume one or two stages in flight");
+  constexpr bool STAGGER = (NW >= 8) && (SRI_SCHED_HINTS != 0);
+  const bool late = STAGGER && wid >= NW / 2;
+
+  issue_setup();
+  for (int i = 0; i < AHEAD; ++i) {
+    if (issued < total_stages) {
+      const uint32_t slot = slot_i;
+      stage_issue();
+      stage_commit(slot);
+      cursor_advance();
+    }
+  }
+
+  uint32_t tile_c = first_tile, kc_c = 0, slot_c = 0;     // compute-side cursor (stage whose k pair 0 comes next)
+  uint32_t ct_c = first_tile % p.col_tiles;                // ... its column tile, stepped by
+  const uint32_t ct_step = tile_step % p.col_tiles;        //     (tile + tile_step) % col_tiles = ct + ct_step (mod col_tiles)
+  uint32_t since_store = 99;                               // waits since a FULL tile's NSTORE stores were issued
+  // Two fragment register sets: (pa, pb) holds k pair 0 of a stage, (qa, qb) k pair 1.  Every fragment read
+  // is issued at least two MFMA groups before its first use, except the early group's read right after a
+  // barrier, which the late group's MFMAs cover.
+  d2 pa[TM], pb[TN], qa[TM], qb[TN];
+  using I2 = std::integral_constant<int, 2>;
+  using IL = std::integral_constant<int, GROUPS - 2>;
+
+  // wait(s) + barrier(s).  Ops of this wave younger than stage s's DMA: the DMA of stage s+1, plus a full
+  // tile's stores if they were issued after stage s's DMA, i.e. within the last two bodies.
+  // Last k chunk of a tile when rows % 16 != 0: rewrite, in the LDS image of the stage that just landed, every
+  // 16-byte piece that holds a k beyond the last row — from plain bounds-checked loads, zero for k >= rows (so
+  // that no foreign value, possibly NaN/Inf, ever meets the zero padding of the operator).  A handful of
+  // elements per column, once per tile, fenced by one extra barrier that both wave groups execute.
+  auto fixup_tail = [&](uint32_t slot, uint32_t tile_s) __attribute__((always_inline)) {
+    const ApplyArgs q = SRI_ARGS_HERE;
+    const size_t last_col = q.m - 1;
+    char* sX = smem + slot * G::STAGE_BYTES + G::A_BYTES;
+    const uint32_t k0 = q.tail_k & ~1u;                      // first k (within the chunk) of the first affected piece
+    const uint32_t fixn = BK - k0;                           // elements per column to rewrite
+    const size_t col0_s = static_cast<size_t>(tile_s % q.col_tiles) * G::BN;
+    const double* const xpanel = q.panels != 0 ? load_uniform_pointer(q.xs, tile_s / q.col_tiles / q.row_blocks) : q.x;
+    const uint32_t kbase = (q.nk - 1) * BK;
+    for (uint32_t idx = tid; idx < G::BN * fixn; idx += G::THREADS) {
+      const uint32_t cc = idx / fixn, kk = k0 + idx % fixn;
+      const size_t col = col0_s + cc;
+      const bool valid = kbase + kk < q.rows;                // a real element of the column (only in the straddling piece)
+      if (valid && col < last_col) continue;                 // delivered by the DMA from its own address
+      double v = 0.0;
+      if (valid && col == last_col) v = xpanel[col * q.ldx + kbase + kk];   // the last column's pieces came from a safe address
+      if constexpr (FOLD) { if (col < q.m && kbase + kk == q.rows) v = q.xb[col]; }
+      const uint32_t pos = (kk >> 1) ^ ((cc >> 1) & SWZ);
+      *reinterpret_cast<double*>(sX + cc * X_ROW_BYTES + pos * 16 + (kk & 1) * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // wait(s) + barrier(s) for the stage (tile_s, kc_s) in ring slot `slot`.  Ops of this wave younger than
+  // stage s's DMA: the DMA of stage s+1, plus a full tile's stores if they were issued after stage s's DMA,
+  // i.e. within the last two bodies.
+  // Last k chunk of a tile when rows % 16 != 0, every tile but the one with the panel's last column: the k slots beyond
+  // the last row hold the first elements of the NEXT column (fetched where they lie — in bounds).  Each wave rewrites
+  // them in the columns of its OWN X pieces — zero, or x_base[col] in the slot FOLD uses (from the side buffer its own
+  // DMA filled) — after its own vmcnt wait and BEFORE the stage's barrier: one lane per column, one 8-byte ds_write per
+  // slot (one slot for the N - 1 = 255, 1023, ... rows of the integration operators), no extra barrier.
+  // Layout of the write, fixed for the whole kernel (two registers): lane -> (column lc of this wave's own X pieces, slot
+  // sl): the wave's CW columns x 64 / CW tail slots per instruction, slot k = min(tail_k + sl, 15) — lanes past the last
+  // slot write slot 15 once more (same value, same address: harmless), so there is no exec mask and, for rows % 16 >=
+  // 16 - 64 / CW (every N = 2^p grid: rows % 16 = 15), no loop and nothing to fetch: round 3 re-read tail_k from the kernarg
+  // segment here — a scalar-load latency in front of the barrier of every tile's last stage.
+  constexpr int CW = 8 * (DMA ? G::X_DMA_PER_WAVE : 1), SPI = 64 / CW;
+  uint32_t tail_addr = 0, tail_more = 0, tail_head = 0;
+  if constexpr (DMA && TAIL) {
+    const uint32_t lc = static_cast<uint32_t>(lane) % CW, sl = static_cast<uint32_t>(lane) / CW;
+    const uint32_t cc = (wid + (lc >> 3) * NW) * 8 + (lc & 7);
+    const uint32_t kk = p.tail_k + sl < static_cast<uint32_t>(BK) ? p.tail_k + sl : static_cast<uint32_t>(BK) - 1;
+    tail_addr = G::A_BYTES + cc * X_ROW_BYTES + (((kk >> 1) ^ ((cc >> 1) & SWZ)) * 16) + (kk & 1) * 8;
+    tail_more = (static_cast<uint32_t>(BK) - p.tail_k + SPI - 1) / SPI - 1;      // wave-uniform, kept in a VGPR: further rounds of SPI slots
+    tail_head = kk == p.tail_k ? 1u : 0u;                       // this lane writes slot k = rows (where FOLD puts x_base) — also the
+    asm volatile("" : "+v"(tail_addr), "+v"(tail_more), "+v"(tail_head));   // clamped lanes when rows % 16 = 15: same value, same address
+  }
+  auto tail_fix_fast = [&](uint32_t slot) __attribute__((always_inline)) {
+    const uint32_t lc = static_cast<uint32_t>(lane) % CW;
+    double v0 = 0.0;
+    if constexpr (XBUF) {
+      v0 = *reinterpret_cast<const double*>(xb_side + (tseq_c & 1u) * (NW * G::XB_WAVE_BYTES) + wid * G::XB_WAVE_BYTES + lc * 8);
+      v0 = tail_head != 0u ? v0 : 0.0;
+    }
+    *reinterpret_cast<double*>(smem + slot * G::STAGE_BYTES + tail_addr) = v0;
+    const uint32_t more = __builtin_amdgcn_readfirstlane(tail_more);
+    if (more != 0) {                                            // rows % 16 < 16 - SPI: rare shapes, may take their time
+      const uint32_t tail_k = p.tail_k, sl = static_cast<uint32_t>(lane) / CW;
+      const uint32_t cc = (wid + (lc >> 3) * NW) * 8 + (lc & 7);
+      for (uint32_t r = 1; r <= more; ++r) {
+        uint32_t kk = tail_k + sl + r * SPI;
+        kk = kk < static_cast<uint32_t>(BK) ? kk : static_cast<uint32_t>(BK) - 1;
+        *reinterpret_cast<double*>(smem + slot * G::STAGE_BYTES + G::A_BYTES + cc * X_ROW_BYTES + (((kk >> 1) ^ ((cc >> 1) & SWZ)) * 16) + (kk & 1) * 8) = 0.0;
+      }
+    }
+  };
+  auto wait_stage = [&](auto refill_tag, uint32_t slot, uint32_t kc_s, uint32_t tile_s) __attribute__((always_inline)) {
+    bool fix_fast = false, fix_edge = false;
+    if constexpr (DMA && TAIL) {
+      // (ct_c == last column tile, kept by advance_compute(): a `tile % col_tiles` here is a dozen vector-ALU
+      // instructions — hipcc divides on the float pipe — and was if-converted into EVERY stage: -2.5 %)
+      if (kc_s + 1 == p.nk) {
+        fix_edge = !LEAN && ct_c + 1 == p.col_tiles;
+        fix_fast = !fix_edge;
+      }
+    }
+    // One fused `s_waitcnt vmcnt(N) lgkmcnt(0)` in front of the barrier wherever nothing has to happen between the two
+    // waits: splitting it into two instructions measured 0.9 % slower on the headline shape (profiles/r03_ab_wait_split.log).
+    auto fused = [&]() __attribute__((always_inline)) {
+      if (decltype(refill_tag)::value) {
+        if (since_store < static_cast<uint32_t>(AHEAD)) wait_stage_and_barrier<W_BOUNDARY>(); else wait_stage_and_barrier<W_STEADY>();
+      } else {
+        wait_stage_and_barrier<0>();                       // tail of the stream: fewer stages in flight
+      }
+    };
+    if constexpr (DMA && TAIL) {
+      if (fix_fast && (SRI_TAIL_ABL & 2) == 0) {
+        if (decltype(refill_tag)::value) {
+          if (since_store < static_cast<uint32_t>(AHEAD)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_BOUNDARY) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_STEADY) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr ((SRI_TAIL_ABL & 1) == 0) tail_fix_fast(slot);   // this wave's own pieces have landed: rewrite its columns' tail slots
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        fused();
+      }
+    } else {
+      fused();
+    }
+    if (since_store < 99) ++since_store;
+    if constexpr (DMA && TAIL) {
+      if (fix_edge) fixup_tail(slot, tile_s);
+    }
+    if constexpr (STAMP) { if (st_t1 == 0) st_t1 = __builtin_amdgcn_s_memtime(); }
+  };
+  // Y stores of `tile` + accumulators back to zero
+  // `since_value`: 0 if the stores follow this body's DMA pieces in program order (the next TWO waits have them
+  // behind the awaited stage), 1 if they precede them (only the next wait does).
+  auto finish_tile = [&](uint32_t tile, uint32_t since_value) __attribute__((always_inline)) {
+    if constexpr (STAMP) st_t2 = __builtin_amdgcn_s_memtime();
+    if (store_tile(tile)) {
+      since_store = since_value;
+    } else {
+      if constexpr ((ABL & 4) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // edge tile: unknown store count, drain
+      since_store = 99;
+    }
+    ++tseq_c;
+    if constexpr ((ABL & 256) == 0) {                           // ABL & 256: keep accumulating (what the zeroing costs)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
+      if constexpr (G::STRIP != 0) sacc = zero4;
+    }
+  };
+  auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
+    slot_c = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+    if (++kc_c < p.nk) return false;
+    kc_c = 0;
+    tile_c += tile_step;
+    ct_c += ct_step;                                         // column tile of the next tile, without a division
+    ct_c = ct_c >= p.col_tiles ? ct_c - p.col_tiles : ct_c;
+    return true;
+  };
+  auto flush_pieces = [&](int& piece, auto pieces_tag) __attribute__((always_inline)) {
+    if constexpr (decltype(pieces_tag)::value) {
+#pragma unroll
+      for (; piece < G::DMA_PER_WAVE; ++piece) issue_piece(piece);
+    }
+  };
+
+  const uint32_t steady_end = total_stages > static_cast<uint32_t>(AHEAD) ? total_stages - AHEAD : 0;
+
+  // STAMP builds: cycles per body segment, summed over the steady bodies (s_memtime drains lgkmcnt, so the
+  // numbers are shares, not the product kernel's run time).
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long seg_t = 0;
+  auto seg_start = [&]() __attribute__((always_inline)) { if constexpr (STAMP) seg_t = __builtin_amdgcn_s_memtime(); };
+  auto seg_mark = [&](int k) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      seg[k] += now - seg_t;
+      seg_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // STAMP builds: a cycle-stamped timeline of ONE tile end (the third tile of the workgroup) for one wave of each group:
+  // the body that ends the tile ("state 1": marks 0..5) and the body after it ("state 2": marks 6..11).
+  unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t tl_state = 0;
+  auto tl_begin = [&](bool closes_tile) __attribute__((always_inline)) {
+    if constexpr (STAMP) tl_state = (closes_tile && tseq_c == 2u) ? 1u : (tl_state == 1u ? 2u : 0u);
+  };
+  auto tl_mark = [&](auto ktag) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      constexpr int k = decltype(ktag)::value;
+      if (tl_state != 0u) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (tl_state == 1u) tl[k] = now; else tl[6 + k] = now;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>; using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+
+  if (!late) {
+    // ---------------- early group (or the whole workgroup when STAGGER is off) ----------------------
+    auto body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      seg_start();
+      tl_begin(kc_c + 1 == p.nk);
+      tl_mark(K0{});
+      wait_stage(refill_tag, slot_c, kc_c, tile_c);
+      tl_mark(K1{});
+      seg_mark(0);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      int piece = 0;
+      read_pair(slot_c, 0, pa, pb);
+      strip_read(slot_c, 0);
+      mfma_groups(pa, pb, I0{}, I2{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);
+      if constexpr ((ABL & 8) != 0) abl_read = false;
+      mfma_groups(pa, pb, I2{}, IG{}, piece, PT{});
+      seg_mark(1);
+      strip_read(slot_c, 1);                                       // (one fragment set: k pair 0's last strip MFMA has been issued)
+      mfma_groups(qa, qb, I0{}, IG{}, piece, PT{});
+      flush_pieces(piece, PT{});
+      seg_mark(2);
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+      const uint32_t done_tile = tile_c;
+      tl_mark(K2{});
+      if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); } else seg_mark(3);
+      tl_mark(K3{});
+    };
+    uint32_t s = 0;
+    for (; s < steady_end; ++s) body(std::true_type{});
+    for (; s < total_stages; ++s) body(std::false_type{});
+  } else {
+    // ---------------- late group: shifted by a k pair minus one MFMA group --------------------------
+    // body(s), s >= 1 (entered with k pair 1 of stage s-1 already in (qa, qb)):
+    //   group 0 of (s-1, 1) | wait(s), barrier(s) | read (s, 0) | groups 1.. of (s-1, 1) with the DMA pieces |
+    //   [stage s-1 closed a tile: stores] | groups of (s, 0), reading (s, 1) two groups before the end
+    auto first_body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      wait_stage(refill_tag, slot_c, kc_c, tile_c);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      int piece = 0;
+      read_pair(slot_c, 0, pa, pb);
+      strip_read(slot_c, 0);
+      mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);
+      if constexpr ((ABL & 8) != 0) abl_read = false;
+      mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      strip_read(slot_c, 1);                                       // for the k pair the next body starts with: read BEFORE its barrier
+      flush_pieces(piece, PT{});
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+    };
+    auto body = [&](auto refill_tag) __attribute__((always_inline)) {
+      constexpr bool REFILL = decltype(refill_tag)::value;
+      constexpr bool PIECES = DMA && REFILL && (SRI_SCHED_HINTS != 0);
+      using PT = std::integral_constant<bool, PIECES>;
+      int piece = 0;
+      seg_start();
+      tl_begin(kc_c + 1 == p.nk);
+      tl_mark(K0{});
+      mfma_groups(qa, qb, I0{}, I1{}, piece, std::false_type{});     // (s-1, 1): slot_c still names stage s-1
+      const bool wraps = kc_c + 1 == p.nk;                           // stage s opens the next tile
+      const uint32_t next_slot = slot_c + 1 == NSTAGE ? 0 : slot_c + 1;
+      tl_mark(K1{});
+      wait_stage(refill_tag, next_slot, wraps ? 0u : kc_c + 1, wraps ? tile_c + tile_step : tile_c);
+      tl_mark(K2{});
+      seg_mark(0);
+      const uint32_t rslot = slot_i;
+      if constexpr (REFILL && !PIECES) stage_issue();
+      read_pair(next_slot, 0, pa, pb);                               // (s, 0): landed, consumed 7 groups later
+      mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
+      flush_pieces(piece, PT{});
+      seg_mark(1);
+      const uint32_t done_tile = tile_c;
+      tl_mark(K3{});
+      // (Issuing the late group's DMA pieces half a stage later, out of phase with the early group's, was
+      // measured: no gain.)  The stores follow this body's pieces in program order.
+      if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
+      tl_mark(K4{});
+      strip_read(slot_c, 0);                                         // (s, 0): the strip's one fragment set is free again
+      mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
+      read_pair(slot_c, 1, qa, qb);                                  // (s, 1): used at the top of the next body
+      mfma_groups(pa, pb, IL{}, IG{}, piece, PT{});
+      strip_read(slot_c, 1);                                         // ... and so is this: issued before the next barrier frees the slot
+      seg_mark(2);
+      if constexpr (REFILL) {
+        stage_commit(rslot);
+        cursor_advance();
+      }
+      seg_mark(3);
+      tl_mark(K5{});
+    };
+    uint32_t s = 0;
+    if (steady_end > 0) first_body(std::true_type{}); else first_body(std::false_type{});
+    for (s = 1; s < steady_end; ++s) body(std::true_type{});
+    for (; s < total_stages; ++s) body(std::false_type{});
+    // second k pair of the last stage
+    {
+      int piece = 0;
+      mfma_groups(qa, qb, I0{}, IG{}, piece, std::false_type{});
+      const uint32_t done_tile = tile_c;
+      if (advance_compute()) finish_tile(done_tile, 0u);
+    }
+  }
+
+  if constexpr (EPI == EPI_QUAT) {
+    // One plain store per wave column and workgroup (same-address atomics from 8 XCDs cost ~200 ns each, and small
+    // operators have tens of thousands of tiles); the host takes the maximum of the few hundred partials it reads back.
+    if (p.partial != nullptr && wm == 0) {                       // the tip lanes of the wave are c == 0, g = 0..3
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const double other = __shfl_xor(tip_update, off);
+        tip_update = (other > tip_update || other != other) ? other : tip_update;
+      }
+      if (lane == 0) p.partial[blockIdx.x * WN + wn] = tip_update;
+    }
+  }
+
+  if constexpr (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      unsigned long long* o = p.stamps + static_cast<size_t>(blockIdx.x) * 8;
+      o[0] = st_t0; o[1] = st_t1; o[2] = st_t2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime();
+      o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+      o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+    }
+    // per-segment sums of wave 0 (early group) and wave NW/2 (late group): 2 x 8 words behind the per-WG block
+    if (lane == 0 && (wid == 0 || wid == NW / 2)) {
+      unsigned long long* q = p.stamps + static_cast<size_t>(gridDim.x) * 8 + (static_cast<size_t>(blockIdx.x) * 2 + (wid ? 1 : 0)) * 8;
+      for (int k = 0; k < 6; ++k) q[k] = seg[k];
+      q[6] = total_stages;
+      q[7] = my_tiles;
+      unsigned long long* t = p.stamps + static_cast<size_t>(gridDim.x) * 24 + (static_cast<size_t>(blockIdx.x) * 2 + (wid ? 1 : 0)) * 12;
+      for (int k = 0; k < 12; ++k) t[k] = tl[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Handle
+// ---------------------------------------------------------------------------------------------
+#ifndef SRI_TALL_WAVES
+#define SRI_TALL_WAVES 8             // experiment knob: 16 = four waves per SIMD with 64x32 wave tiles
+#endif
+#if SRI_TALL_WAVES == 4
+// BM 256 x BN 64, 4 waves of 64 x 64, TWO ring slots (80 KiB): two INDEPENDENT workgroups per CU — no barrier couples the
+// wave that issues a tile's Y stores to its partner on the SIMD (experiment, see DESIGN.md "tile ends")
+using GeoTall = Geo<4, 1, 4, 4, 2>;
+#elif SRI_TALL_WAVES == 16
+using GeoTall = Geo<4, 4, 4, 2, 3>;   // BM 256 x BN 128, 16 waves (64x32 each), 144 KiB ring, 1 WG/CU
+#else
+using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring, 1 WG/CU : rows > 128 (N = 256, 1024, ...) unless GeoMid pads less
+#endif
+// BM 128 x BN 128, 4 waves of 64 x 64 (the MFMA : fragment-read ratio of the tall geometry), TWO ring slots (one stage in
+// flight: 64 KiB) so that 2 WG share a CU and cover each other's waits: 64 < rows <= 128, and larger operators whose last 256-row block would be at most half full (create_from_matrix).  Measured at N = 128, 65 536 rods:
+// 0.138 ms against 0.146 ms for the previous 128 x 64 tile with three slots (+5.7 %).  (At N = 256, two row blocks, it is
+// 4 % behind the tall geometry: 0.531 vs 0.509 ms.)
+using GeoMid = Geo<2, 2, 4, 4, 2>;
+using GeoFlat = Geo<1, 4, 4, 1, 3>;   // BM  64 x BN  64, 4 waves,  48 KiB ring, 3 WG/CU : rows <= 64 (N = 16, 64)
+// BM 64 x BN 256, 4 waves of 64 x 64 side by side (GeoMid's wave tile, MFMA : fragment-read ratio and two-slot ring, 80 KiB,
+// 2 WG per CU): the LAST 1-64 rows of an operator whose row count is not a whole number of 128- / 256-row blocks, as a part
+// of its own (round 4, "Parts" below) — a 64-row block at the larger geometries' efficiency instead of a 128- or 256-row
+// block that is mostly padding.  Plain and rank-1-epilogue launches only.
+using GeoWide = Geo<1, 4, 4, 4, 2>;
+// BM 32 x BN 256: the same for a last part of at most 32 rows — half the MFMAs of GeoWide per column tile; it streams the
+// panel at the copy rate (8 flop per byte), which is the floor of any separate launch over the last rows
+using GeoWide32 = Geo<1, 4, 2, 4, 2>;
+
+// GeoTall + the strip: 272 x 128 per tile, 150 KiB ring — the last 256-row block of an operator of 256 a + r rows, r <= 16,
+// with those r rows riding along (+ 2 MFMAs per 32 and two fragment reads per k pair and wave): no second pass over the panel
+using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
+
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5 };
+
+}  // namespace sri
+
+namespace sri {
+
+// `w` (optional, rows % 16 != 0 only): the rank-1 factor, packed negated as operator column k = rows — the free slot of
+// the last k chunk; the kernel puts x_base[col] (or 0 for a plain apply) into the matching slot of the X image.
+// `A` points at the first of `rows` rows to pack (the whole operator, or one part of it: "Parts" below); all `kdim` columns.
+template <class G>
+static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+                          std::vector<double>& out) {
+  out.assign(static_cast<size_t>(row_blocks) * nk * G::A_ROWS * BK, 0.0);
+  size_t o = 0;
+  for (uint32_t rb = 0; rb < row_blocks; ++rb)
+    for (uint32_t kc = 0; kc < nk; ++kc)
+      for (int tile = 0; tile < G::A_ROWS / 16; ++tile)
+        for (int j = 0; j < KPAIRS; ++j)
+          for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 2; ++e, ++o) {
+              // (the strip's tile, if the geometry has one, follows the BM rows of its — only — row block: row slot = row)
+              const uint32_t row = tile < G::BM / 16 ? rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15)
+                                                     : rb * G::BM + G::BM + static_cast<uint32_t>(l & 15);
+              const uint32_t k = kc * BK + k_of(asc, j, l >> 4, e);
+              if (row < rows && k < kdim) out[o] = A[row + static_cast<size_t>(k) * lda];
+              else if (w != nullptr && row < rows && k == kdim) out[o] = -w[row];
+            }
+#ifdef SRI_TEST_CORRUPT_OPERATOR
+  // `make broken` only (never in libsri_hip.so): one operator entry off by 2^-20 relative, so that a test can show
+  // bench.py's parity gate turning a wrong kernel into a non-zero exit code.
+  for (double& v : out)
+    if (v != 0.0) { v *= 1.0 + 0x1p-20; break; }
+#endif
+}
+
+// Residency of each kernel variant (blocks per CU), per device.  Filled by prepare() at handle creation so
+// that a launch performs no attribute or occupancy calls: sri_apply() only enqueues a kernel and is safe
+// inside a stream capture (HIP graph).
+// Written under prepare()'s lock (handles may be created from several host threads, on the same or on different
+// devices), read lock-free by launch().
+constexpr int kMaxDevices = 16;
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
+static std::atomic<int>& residency(int dev) {
+  static std::atomic<int> blocks_per_cu[kMaxDevices] = {};
+  return blocks_per_cu[dev];
+}
+
+inline std::mutex& prepare_mutex() {   // (one mutex for every translation unit that instantiates kernels)
+  static std::mutex m;
+  return m;
+}
+
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
+static int prepare(int dev) {
+  if (dev < 0 || dev >= kMaxDevices) return SRI_EUNSUPPORTED;
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_acquire) != 0) return SRI_OK;
+  std::lock_guard<std::mutex> lock(prepare_mutex());
+  if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
+  const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>;
+  constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : 0;        // FOLD on the LDS-DMA path: x_base side buffer at the end
+  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
+  static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
+  // the attribute is the most any launch of this kernel may ask for
+  constexpr int lds_max = EPI != EPI_QUAT ? lds : (G::lds_bytes_quat(4) + xb <= 160 * 1024 ? G::lds_bytes_quat(4) + xb : G::lds_bytes_quat(2) + xb);
+  SRI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+  int nb = 0;
+  SRI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, G::THREADS, lds));
+  residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).store(nb < 1 ? 1 : nb, std::memory_order_release);
+  return SRI_OK;
+}
+
+// Persistent launch: as many workgroups as the chip keeps resident (CUs x blocks/CU), never more
+// than there are tiles.
+template <class G, bool DMA, bool RANK1, bool TAIL, int EPI = EPI_NONE, int BUFS = 0, bool ASC = false, bool LEAN = false>
+static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32_t max_wgs, hipStream_t stream,
+                  uint32_t* partials = nullptr) {
+  const int per_cu = residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_acquire);
+  if (per_cu == 0) return SRI_EUNSUPPORTED;            // prepare() did not run for this device
+  const size_t tiles = col_tiles * args.row_blocks * (args.panels != 0 ? args.panels : 1u);
+  if (tiles == 0) return SRI_OK;
+  if (tiles > 0x7fffffffull) return SRI_EUNSUPPORTED;
+  args.col_tiles = static_cast<uint32_t>(col_tiles);
+  args.side_bufs = BUFS;
+  size_t resident = static_cast<size_t>(num_cus) * per_cu;
+  if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
+  const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
+  // XCD-grouped walk (see the kernel): only where it is well defined — a full grid that splits into 8 XCDs x row blocks,
+  // at least one round of column tiles for everybody — and wanted (SRI_TILE_ORDER=0 keeps the plain walk: A/B, profiles)
+  static const bool order_off = [] { const char* v = std::getenv("SRI_TILE_ORDER"); return v && v[0] == '0'; }();
+  args.tile_order = (!order_off && args.panels == 0 && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
+  if (partials != nullptr) {
+    if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
+    *partials = grid * G::WN;
+  }
+  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + ((DMA && RANK1 && TAIL) ? G::XB_BYTES : 0);
+  SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>), dim3(grid), dim3(G::THREADS), lds, stream, args));
+  return SRI_OK;
+}
+
+}  // namespace sri
+
+#endif  // SRI_APPLY_KERNEL_H

@@ -1,0 +1,47 @@
+// sri_apply_strip.hip — the 256-row geometry with a 16-row strip (GeoTallStrip): the last block of an operator of 256 a + r rows, r <= 16
+#include "sri_apply_kernel.h"
+#include "sri_apply_geometries.h"
+
+namespace sri {
+
+int prepare_strip(int dev) {
+  int rc = prepare<GeoTallStrip, true, false, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, false>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, false, EPI_NONE, 0, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, true, true, EPI_NONE, 0, false, true>(dev);
+  if (rc == SRI_OK) rc = prepare<GeoTallStrip, true, false, true, EPI_NONE, 0, true, true>(dev);
+  return rc;
+}
+
+int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean) {
+  using GS = GeoTallStrip;
+  const size_t col_tiles = (args.m + GS::BN - 1) / GS::BN;
+  const int cus = h->num_cus, dev = h->device;
+  const uint32_t cap = h->max_workgroups;
+  const bool tail = args.tail_k != 0;
+  if (args.row_blocks != 1) return SRI_EUNSUPPORTED;                 // the strip belongs to its part's only row block
+  if (h->ascending) {
+    if (rank1) return SRI_EUNSUPPORTED;
+    if (tail && lean) return launch<GS, true, false, true, EPI_NONE, 0, true, true>(args, col_tiles, dev, cus, cap, stream);
+    return tail ? launch<GS, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
+                : launch<GS, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
+  }
+  if (tail && lean) return rank1 ? launch<GS, true, true, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
+                                 : launch<GS, true, false, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream);
+  if (rank1) return tail ? launch<GS, true, true, true>(args, col_tiles, dev, cus, cap, stream)
+                         : launch<GS, true, true, false>(args, col_tiles, dev, cus, cap, stream);
+  return tail ? launch<GS, true, false, true>(args, col_tiles, dev, cus, cap, stream)
+              : launch<GS, true, false, false>(args, col_tiles, dev, cus, cap, stream);
+}
+
+
+void pack_strip(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+                std::vector<double>& out) {
+  pack_operator<GeoTallStrip>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
+
+}  // namespace sri

@@ -153,7 +153,7 @@ def test_bench_exits_nonzero_when_the_parity_gate_fails():
     assert d["parity"]["ok"] is False and d["parity"]["bit_exact_vs_cpu_model_of_the_kernel"] is False
     assert "PARITY GATE FAILED" in d["_stderr"]
     csrc = os.path.join(ROOT, "experimental_gpu_programming_for_a_spectral_numerical_integration_amd", "csrc")
-    subprocess.check_call(["make", "-C", csrc, "broken"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-j4", "-C", csrc, "broken"], stdout=subprocess.DEVNULL)
     d = _run([sys.executable, "bench.py", "--no-verify"] + SMALL,
              env={"SRI_HIP_LIBRARY": os.path.join(ROOT, "build", "libsri_hip_broken.so")}, rc=2)
     assert d["parity"]["ok"] is False and d["parity"]["failures"]

@@ -43,7 +43,7 @@ def pmc(sub):
 
 res = {"source": "tools/profile_rod.sh: rocprofv3 --kernel-trace --pmc <one group per pass> -- python tools/step_bench.py --n 256 "
                  "--rods 65536 (255-row integration operator, per-launch means). Kernel template arguments: <Geo, DMA, RANK1, TAIL, "
-                 "STAMP, ABL, EPI, ASC>; EPI = 1 is the fused Picard step. FETCH_SIZE is in KiB and counts 128-B requests as 64 B on "
+                 "STAMP, ABL, EPI, ASC, LEAN>; EPI = 1 is the fused Picard step, LEAN the twin without edge handling. FETCH_SIZE is in KiB and counts 128-B requests as 64 B on "
                  "gfx950 (x2, MI355X_MICROARCH.md HBM); WRITE_SIZE in KiB.",
        "kernels": {}}
 for sub in ("lds", "fetch", "write"):
@@ -64,8 +64,8 @@ for k, d in res["kernels"].items():
         d["hbm_read_bytes_corrected_x2"] = d["FETCH_SIZE"] * 1024 * 2
         d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
         d["hbm_bytes"] = d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"]
-        targs = k[k.rfind(">,") + 2:k.rfind(">(")].split(",")          # ... DMA, RANK1, TAIL, STAMP, ABL, EPI, ASC
-        fused = len(targs) >= 2 and targs[-2].strip() == "1"
+        targs = k[k.rfind(">,") + 2:k.rfind(">(")].split(",")          # ... DMA, RANK1, TAIL, STAMP, ABL, EPI, ASC, LEAN
+        fused = len(targs) >= 3 and targs[-3].strip() == "1"
         d["fused_picard_step"] = fused
         d["algorithmic_bytes"] = alg["fused step"] if fused else alg["plain / integrate"]
         d["hbm_over_algorithmic"] = d["hbm_bytes"] / d["algorithmic_bytes"]
