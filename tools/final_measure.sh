@@ -24,5 +24,6 @@ python tools/step_bench.py > gpurun_out/${tag}_step_bench.json 2>/dev/null; echo
 python tools/parity_report.py > gpurun_out/${tag}_parity_report.json 2>/dev/null; echo "parity_report rc=$?"
 tools/profile_rod.sh ${tag} > gpurun_out/prof_rod_${tag}.log 2>&1; echo "profile_rod rc=$?"
 fi
-cp profiles/${tag}_* profiles/hbm_traffic_* gpurun_out/ 2>/dev/null
+# (only what THIS run wrote into profiles/ on the box: never overwrite the fresh bench lines with committed files of the same name)
+cp profiles/${tag}_*rocprofv3* profiles/${tag}_fused_step_pmc.json profiles/hbm_traffic_* gpurun_out/ 2>/dev/null
 grep -h -o '"frac": [0-9.]*' gpurun_out/${tag}_bench_*.json

@@ -18,13 +18,14 @@ out = ["# Register / spill / occupancy report of every shipped variant of sri::a
        "# `make -C <pkg>/csrc asm` (hipcc -Rpass-analysis=kernel-resource-usage, --offload-arch=gfx950) + tools/resource_usage.py.",
        "# lane/VALU: v_readlane + v_writelane (scalar-register spill traffic) and all other vector-ALU instructions in the basic",
        "# blocks of the ISA that hold at least one v_mfma (stage bodies AND tile ends; the steady stage bodies are the blocks with",
-       "# 28-64 MFMAs and no global_store).  EPI 1 = fused quaternion step, ASC = ascending k order.",
-       f"{'geometry':28s} DMA R1 TAIL EPI ASC | VGPR SGPR Sspill Vspill scratch occ | lane / VALU in MFMA blocks | lane ops in store-free MFMA blocks"]
+       "# 28-64 MFMAs and no global_store).  EPI 1 = fused quaternion step, ASC = ascending k order, LEAN = the twin of a TAIL variant",
+       "# without the edge handling of the panel's last column (launched where run() finds the bytes past the panel readable).",
+       f"{'geometry':28s} DMA R1 TAIL EPI ASC LEAN | VGPR SGPR Sspill Vspill scratch occ | lane / VALU in MFMA blocks | lane ops in store-free MFMA blocks"]
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = b.split("\n")[0].split(" ")[0]
     g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
     mg = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEE", name)
-    m = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi\dEEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)", name)
+    m = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi\dEEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)", name)
     if mg is None or m is None:
         continue
     i = isa.index(name + ":")
@@ -50,7 +51,7 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
             if t and not t.startswith((";", ".")):
                 cur.append(t)
     flush(cur)
-    out.append(f"{GEO.get(','.join(mg.groups()), ','.join(mg.groups())):28s} {m.group(6):>3s} {m.group(7):>2s} {m.group(8):>4s} {m.group(11):>3s} {m.group(12):>3s} | "
+    out.append(f"{GEO.get(','.join(mg.groups()), ','.join(mg.groups())):28s} {m.group(6):>3s} {m.group(7):>2s} {m.group(8):>4s} {m.group(11):>3s} {m.group(12):>3s} {m.group(13):>4s} | "
                f"{g('VGPRs'):>4s} {g('TotalSGPRs'):>4s} {g('SGPRs Spill'):>6s} {g('VGPRs Spill'):>6s} {g(SCR):>7s} {g(OCC):>3s} | "
                f"{lane:4d} / {valu:4d} | {steady_lane}")
 text = "\n".join(out) + "\n"
