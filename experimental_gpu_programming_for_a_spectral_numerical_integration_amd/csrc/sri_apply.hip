@@ -62,9 +62,13 @@ static int check_device(int device, int* num_cus = nullptr) {
   return SRI_OK;
 }
 
+// `rows`: the operator's column count = the row count of the panels it is applied to (k); `rows_out` (0: square): its row count
+// = the row count of the result.  Rectangular operators are internal (the rod pipeline's interpolation, §7): one geometry, no parts.
 static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A, size_t lda, const double* w_host,
-                              int which, int device) {
-  if (out == nullptr || A == nullptr || rows < 1 || lda < rows) return SRI_EINVAL;
+                              int which, int device, uint32_t rows_out = 0) {
+  if (rows_out == 0) rows_out = rows;
+  const bool square = rows_out == rows;
+  if (out == nullptr || A == nullptr || rows < 1 || lda < rows_out) return SRI_EINVAL;
   *out = nullptr;
   int num_cus = 0;
   int rc = check_device(device, &num_cus);
@@ -78,21 +82,24 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->device = device;
   h->num_cus = num_cus;
   h->rows = rows;
+  h->rows_out = rows_out;
   h->which = which;
   // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry
   // (0.77 of the MFMA peak at K = 128, 0.86 from K = 384 on: tile ends amortise over K) is the better choice whenever it
   // saves a half-empty 256-row block, i.e. when the last 256-row block would hold at most 128 rows — measured N = 320:
   // 0.54 -> 0.71, N = 384: 0.66 -> 0.86 of the peak (profiles/r03_sweep_n.jsonl).
-  const bool half_empty_last_block = rows > 256 && (rows - 1) % 256 < 128;
-  h->geo = rows <= 64 ? GEO_FLAT : ((rows <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
+  const bool half_empty_last_block = rows_out > 256 && (rows_out - 1) % 256 < 128;
+  h->geo = rows_out <= 64 ? GEO_FLAT : ((rows_out <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
+  // (tiles of one or two k chunks: the fused step needs four side buffers, which the 256-row geometry's ring leaves no room for)
+  if (!square && h->geo == GEO_TALL && (rows + BK - 1) / BK < 3) h->geo = GEO_MID;
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
   // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant exists for
   // the two larger geometries — what is reported is always what pack_operator() and dispatch() use.
-  h->ascending = h->geo != GEO_FLAT && rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
+  h->ascending = square && h->geo != GEO_FLAT && rows > kAscendingAboveRows && which != SRI_OP_DNN_INV;
   h->bm = h->geo == GEO_FLAT ? GeoFlat::BM : (h->geo == GEO_MID ? GeoMid::BM : GeoTall::BM);
   h->nk = (rows + BK - 1) / BK;
-  h->row_blocks = (rows + h->bm - 1) / h->bm;
+  h->row_blocks = (rows_out + h->bm - 1) / h->bm;
   rc = h->geo == GEO_FLAT ? prepare_flat(device) : (h->geo == GEO_MID ? prepare_mid(device) : prepare_tall(device));
   if (rc != SRI_OK) {
     delete h;
@@ -102,9 +109,9 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   std::vector<double> packed;
   try {
     const double* wf = (rows % BK != 0) ? w_host : nullptr;
-    if (h->geo == GEO_FLAT) pack_flat(A, lda, rows, rows, h->nk, h->row_blocks, wf, false, packed);
-    else if (h->geo == GEO_MID) pack_mid(A, lda, rows, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
-    else pack_tall(A, lda, rows, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
+    if (h->geo == GEO_FLAT) pack_flat(A, lda, rows_out, rows, h->nk, h->row_blocks, wf, false, packed);
+    else if (h->geo == GEO_MID) pack_mid(A, lda, rows_out, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
+    else pack_tall(A, lda, rows_out, rows, h->nk, h->row_blocks, wf, h->ascending, packed);
   } catch (const std::bad_alloc&) {
     delete h;
     return SRI_ENOMEM;
@@ -120,7 +127,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   };
   // SRI_APPLY_NO_SMALL=1 (diagnostics, A/B timing): keep 64-row operators on the general kernel
   const char* no_small = std::getenv("SRI_APPLY_NO_SMALL");
-  if (small_supported(rows) && !(no_small && no_small[0] == '1')) {
+  if (square && small_supported(rows) && !(no_small && no_small[0] == '1')) {
     rc = small_prepare(device);
     if (rc != SRI_OK) return fail(rc);
     std::vector<double> sp;
@@ -148,7 +155,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     const char* no_parts = std::getenv("SRI_APPLY_NO_PARTS");
     const char* no_strip = std::getenv("SRI_APPLY_NO_STRIP");       // A/B: thin last rows as a part of their own instead of a strip
     int np = 0;
-    if (!(no_parts && no_parts[0] == '1')) {
+    if (square && !(no_parts && no_parts[0] == '1')) {
       if (units >= 5 && units % 4 == 1) {
         const uint32_t full = 256 * (units / 4), rest = rows - full;
         if (rest <= 16 && !(no_strip && no_strip[0] == '1')) {
@@ -211,11 +218,13 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     if (h->num_parts != 0) padded = std::max<size_t>(padded, static_cast<size_t>(rows) + 256);
     if (hipMalloc(&h->d_w, padded * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
     if (hipMemset(h->d_w, 0, padded * sizeof(double)) != hipSuccess) return fail(SRI_EHIP);                  // (zero padding)
-    if (hipMemcpy(h->d_w, w_host, rows * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+    if (hipMemcpy(h->d_w, w_host, rows_out * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
   }
   *out = h;
   return SRI_OK;
 }
+
+constexpr int kWhichInterpolation = -3;   // sri_apply_handle::which of create_interpolation_operator()
 
 struct ManyPanels {
   const double* const* xs;   // device array of `count` device pointers
@@ -226,7 +235,7 @@ struct ManyPanels {
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
                hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr, uint32_t* partials = nullptr,
                const ManyPanels* many = nullptr) {
-  if (h == nullptr || ldx < h->rows || ldy < h->rows) return SRI_EINVAL;
+  if (h == nullptr || ldx < h->rows || ldy < h->rows_out) return SRI_EINVAL;
   if (many == nullptr && M > 0 && (dX == nullptr || dY == nullptr)) return SRI_EINVAL;
   if (many != nullptr && (many->xs == nullptr || many->ys == nullptr || d_xb != nullptr || d_tips != nullptr || quat != nullptr)) return SRI_EINVAL;
   if (M == 0 || (many != nullptr && many->count == 0)) return SRI_OK;
@@ -270,7 +279,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.ldy = ldy;
   args.m = M;
   args.rows = h->rows;
-  args.rows_out = h->rows;
+  args.rows_out = h->rows_out;
   args.nk = h->nk;
   args.row_blocks = h->row_blocks;
   args.col_tiles = 0;   // set by launch()
@@ -286,7 +295,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // the register-staged build.
   const bool dma = h->rows >= 16;
   // the LDS-DMA pieces address a tile as a uniform 64-bit base + a 32-bit lane offset: 128 columns must span < 4 GiB
-  if (dma && (static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * 128ull + static_cast<unsigned long long>(h->rows) * 8ull) >= (1ull << 32))
+  if (dma && (static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * 128ull + static_cast<unsigned long long>(std::max(h->rows, h->rows_out)) * 8ull) >= (1ull << 32))
     return SRI_EUNSUPPORTED;
   args.tail_k = h->rows % 16;
   // (many panels: their bases are only known on the device — plain stores)
@@ -335,7 +344,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials) {
-  if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
+  if (h == nullptr || (h->which != SRI_OP_DNN_INV && h->which != kWhichInterpolation) || d_x_base == nullptr) return SRI_EINVAL;
   if (quat.partial != nullptr && partials == nullptr) return SRI_EINVAL;
   return run(h, dG, ldg, dG_next, ldn, M, d_x_base, static_cast<hipStream_t>(stream), d_tips, &quat, partials);
 }
@@ -345,6 +354,13 @@ int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY,
   return run(h, dX, ldx, dY, ldy, M, d_x_base, static_cast<hipStream_t>(stream));
 }
 
+// rows_out x kdim operator with rank-1 weights w (rows_out; result = A X - w x_base^T), for integrate_quat_step only:
+// G = 1/2 A(K) (A X - w x_base^T) with A a coarse-to-fine interpolation matrix is the rod pipeline's prolongation (sri_rod.hip)
+int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t kdim, const double* A, size_t lda, const double* w, int device) {
+  if (w == nullptr || kdim < 16 || kdim % BK == 0) return SRI_EUNSUPPORTED;      // (the rank-1 term rides in the free slot of the last k chunk)
+  return create_from_matrix(out, kdim, A, lda, w, kWhichInterpolation, device, rows_out);
+}
+
 uint32_t max_partials(const sri_apply_t* h) { return h ? static_cast<uint32_t>(h->num_cus) * 8u * 4u : 0; }
 
 uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 0; }
@@ -352,7 +368,7 @@ uint32_t padded_rows(const sri_apply_t* h) { return h ? h->row_blocks * h->bm : 
 // w = Dn_NN^-1 Dn_IN of an integration handle exactly as the kernel applies it (rows doubles, host).
 int ivp_weights(const sri_apply_t* h, double* w_host) {
   if (h == nullptr || w_host == nullptr || h->which != SRI_OP_DNN_INV || h->d_w == nullptr) return SRI_EINVAL;
-  return hipMemcpy(w_host, h->d_w, sizeof(double) * h->rows, hipMemcpyDeviceToHost) == hipSuccess ? SRI_OK : SRI_EHIP;
+  return hipMemcpy(w_host, h->d_w, sizeof(double) * h->rows_out, hipMemcpyDeviceToHost) == hipSuccess ? SRI_OK : SRI_EHIP;
 }
 
 }  // namespace sri

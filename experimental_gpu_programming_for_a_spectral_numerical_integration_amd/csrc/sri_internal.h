@@ -53,6 +53,8 @@ struct QuatEpilogue {
 // `partials`: in = capacity of quat.partial (entries), out = entries written by this launch.
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials = nullptr);
+// a rows_out x kdim operator with rank-1 weights (kdim >= 16, kdim % 16 != 0), usable with integrate_quat_step only — sri_apply.hip
+int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t kdim, const double* A, size_t lda, const double* w, int device);
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 int ivp_weights(const sri_apply_t* h, double* w_host);   // w = Dn_NN^-1 Dn_IN as the handle applies it (rows doubles); `device` current
@@ -119,7 +121,8 @@ int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY,
 // The apply handle (sri_apply.hip creates, launches and destroys it; sri_host_panels.hip hangs its pipe on it).
 struct sri_apply_handle {
   int device = 0;
-  uint32_t rows = 0;
+  uint32_t rows = 0;             // columns of the operator = rows of the panels it is applied to (k)
+  uint32_t rows_out = 0;         // rows of the operator = rows of the result (== rows for every operator of the C ABI)
   int which = -1;
   int geo = 0;
   uint32_t bm = 0, nk = 0, row_blocks = 0;

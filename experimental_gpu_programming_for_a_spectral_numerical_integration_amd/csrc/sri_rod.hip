@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -293,6 +294,8 @@ struct sri_rod_handle {
   bool emit_position_rhs = false;         // set by sri_rod_integrate: the confirmation pass also writes b = R(q) e1 into d_B
   sri::ResidentRod* coarse = nullptr;     // N > 64: on-chip solver on a 32-node grid, predictor of the fine fixed point
   double* d_PT = nullptr;                 // its barycentric interpolation matrix to the fine unknown nodes, transposed
+  sri_apply_t* prolong = nullptr;         // the same matrix as an apply handle (m x 31, the base node's column as the rank-1 term): the
+                                          // prolongation as ONE fused step on the MFMA pipe; null -> prolong_rhs_kernel (vector ALU)
   bool use_predictor = true;
 };
 
@@ -421,6 +424,20 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
         hipMemcpy(h->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
       return SRI_ENOMEM;
     }
+    // Round 4: G^0 = 1/2 A(K) (P [Q_c; q0]) is exactly a fused step — operator P[:, :31] (m x 31), the base node's column
+    // P[:, 31] as the rank-1 weights (result = A X - w x_base^T with w = -P[:, 31]), the right-hand side formed in the store
+    // stage, the tip row emitted on the way — so the interpolation runs on the MFMA pipe (bound by writing G^0) instead of
+    // one vector-ALU fused multiply-add chain per fine node and rod.  SRI_ROD_VALU_PROLONG=1 keeps the old kernel (A/B).
+    const char* valu = std::getenv("SRI_ROD_VALU_PROLONG");
+    if (!(valu && valu[0] == '1')) {
+      constexpr uint32_t mc = sri::kCoarseN - 1;
+      std::vector<double> Pm(static_cast<size_t>(h->m) * mc), wneg(h->m);
+      for (uint32_t i = 0; i < h->m; ++i) {
+        for (uint32_t j = 0; j < mc; ++j) Pm[i + static_cast<size_t>(j) * h->m] = P[i + static_cast<size_t>(j) * n];
+        wneg[i] = -P[i + static_cast<size_t>(mc) * n];
+      }
+      if (sri::create_interpolation_operator(&h->prolong, h->m, mc, Pm.data(), h->m, wneg.data(), device) != SRI_OK) h->prolong = nullptr;
+    }
   }
   return SRI_OK;
 }
@@ -447,6 +464,7 @@ int sri_rod_destroy(sri_rod_t* h) {
   if (h->resident) sri::resident_destroy(h->resident);
   if (h->coarse) sri::resident_destroy(h->coarse);
   if (h->d_PT) (void)hipFree(h->d_PT);
+  if (h->prolong) sri_apply_destroy(h->prolong);
   if (h->integ) sri_apply_destroy(h->integ);
   double* bufs[] = {h->d_nodes, h->d_leg, h->d_K, h->d_G, h->d_Qa, h->d_B, h->d_xb4, h->d_xb3, h->d_tips};
   for (double* b : bufs)
@@ -562,9 +580,15 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     int rcc = sri::resident_integrate(h->coarse, d_qe, rods, qi, nullptr, dQc, mc, nullptr, 0, 0.25 * tol, coarse_iters, &itc, &updc,
                                       stream_);
     if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
-      const dim3 grid(static_cast<unsigned>((rods + sri::kProlongRods - 1) / sri::kProlongRods), (m + 255) / 256);
-      ROD_HIP(sri::launch_kernel(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
-                         qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, ldw, h->d_tips + cols));
+      if (h->prolong != nullptr) {
+        sri::QuatEpilogue epi{d_qe, h->d_leg};
+        const int rp = sri::integrate_quat_step(h->prolong, dQc, mc, h->d_xb4, epi, cur, ldw, cols, h->d_tips + cols, stream);
+        if (rp != SRI_OK) return rp;
+      } else {
+        const dim3 grid(static_cast<unsigned>((rods + sri::kProlongRods - 1) / sri::kProlongRods), (m + 255) / 256);
+        ROD_HIP(sri::launch_kernel(sri::prolong_rhs_kernel, grid, dim3(256), 0, stream, m, rods, dQc, static_cast<size_t>(mc), h->d_PT, qi[0],
+                           qi[1], qi[2], qi[3], d_qe, h->d_nodes, cur, ldw, h->d_tips + cols));
+      }
       predicted = true;
     } else if (rcc != SRI_OK && rcc != SRI_ENOTCONVERGED) {
       return rcc;
