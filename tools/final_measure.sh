@@ -6,6 +6,7 @@
 tag=${1:-r04}
 part=${2:-all}
 mkdir -p gpurun_out
+touch gpurun_out/.final_measure_start
 if [ "$part" = "a" ] || [ "$part" = "all" ]; then
 python bench.py > gpurun_out/${tag}_bench_n256.json 2> gpurun_out/${tag}_bench_n256.err; echo "bench cfg3 rc=$?"
 python bench.py --config 2 --steps 20000 --warmup 1000 > gpurun_out/${tag}_bench_cfg2.json 2>/dev/null; echo "bench cfg2 rc=$?"
@@ -24,6 +25,7 @@ python tools/step_bench.py > gpurun_out/${tag}_step_bench.json 2>/dev/null; echo
 python tools/parity_report.py > gpurun_out/${tag}_parity_report.json 2>/dev/null; echo "parity_report rc=$?"
 tools/profile_rod.sh ${tag} > gpurun_out/prof_rod_${tag}.log 2>&1; echo "profile_rod rc=$?"
 fi
-# (only what THIS run wrote into profiles/ on the box: never overwrite the fresh bench lines with committed files of the same name)
-cp profiles/${tag}_*rocprofv3* profiles/${tag}_fused_step_pmc.json profiles/hbm_traffic_* gpurun_out/ 2>/dev/null
+# only what THIS run wrote into profiles/ on the box (summaries, traffic records): a committed file of the same name that this run
+# did not refresh must never travel back over a fresh one
+find profiles -maxdepth 1 -type f -newer gpurun_out/.final_measure_start -exec cp {} gpurun_out/ \;
 grep -h -o '"frac": [0-9.]*' gpurun_out/${tag}_bench_*.json
