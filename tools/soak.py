@@ -18,7 +18,8 @@ bad = 0
 noise = torch.rand((1 << 24,), dtype=torch.float64, device="cuda")
 for n, which, M in [(256, 0, 33000), (256, 1, 20001), (1024, 0, 3000), (1024, 1, 1500), (64, 0, 16384), (64, 0, 3001), (64, 0, 70000),
                     (128, 0, 9000), (100, 0, 5000), (16, 0, 9999), (512, 0, 4000), (256, 2, 7777),
-                    (320, 0, 9000), (384, 1, 5001), (640, 0, 3000), (513, 0, 2500), (897, 1, 1500)]:   # several 128-row blocks, both k orders
+                    (320, 0, 9000), (384, 1, 5001), (640, 0, 3000), (513, 0, 2500), (897, 1, 1500),   # several 128-row blocks, both k orders
+                    (257, 0, 9000), (258, 1, 7001), (1025, 0, 2100), (300, 0, 6000), (160, 0, 9000), (273, 1, 4000)]:   # round 4: strip, parts, lean twins
     op = sri.SpectralApply(n, which)
     X = torch.rand((M, op.rows), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     tips = torch.empty(M, dtype=torch.float64, device="cuda")
