@@ -738,6 +738,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // (the host guarantees that 128 columns of Y span < 4 GiB)
   uint32_t ylane = static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
   asm volatile("" : "+v"(ylane));
+  // ... and of the fused quaternion epilogue's: this lane's rod is 4g columns in, its component r one column further each
+  uint32_t ylane_q = 4u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
+  asm volatile("" : "+v"(ylane_q));
   // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
@@ -892,6 +895,102 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
     for (int t = 0; t < TM / 2; ++t)
       p1[t] = *reinterpret_cast<const d2*>(side + G::QE_BYTES + (wm * (TM * 16) + 2 * c + 32 * t) * 8);
+    if constexpr (SRI_STORE_SADDR != 0 && DMA) {
+      // Round 4: the counted path — every column of the tile exists and this WAVE's 64 rows do too, except possibly the very
+      // last one — stores like the plain epilogue does: wave-uniform base per column (scalar ALU), one constant per-lane offset
+      // for the whole kernel (rod 4g + component r is column 4g + r: `ylane_q`), the row pair in the immediate.
+      // Before: a 64-bit VALU multiply-add chain per store (~190 of the epilogue's 280 vector-ALU instructions per tile).
+      // (Measured twice: on the edge-safe odd-row-count variant it drowned in register spills — 14 VGPRs — and was dropped; on
+      // the LEAN twin, which has registers to spare, it is worth 2.7 % of the fused step: profiles/r04_ab_epi_saddr_stores.log.)
+      // Half-empty last row pair (255, 1023 ... rows; TAIL builds only): the pair goes out as a 16-byte store under an exec
+      // mask without the lane that holds the last row, followed by that lane's 8 bytes — both masks are scalar values worked
+      // out once per tile (all lanes / no lane for every other wave: an exec = 0 store is a no-op that still retires through
+      // vmcnt), so the sequence has no branch and every wave issues the same number of store instructions (QSTORE).
+      if ((col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + 1)) {
+        const size_t ldy8 = q.ldy * sizeof(double);
+        char* const ybase = reinterpret_cast<char*>(q.y) + (col0_c + wn * (TN * 16)) * ldy8 +
+                            (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
+        [[maybe_unused]] uint32_t mask_pair = 0xffffffffu, mask_last = 0u;   // per 32 lanes (two quarter-waves); same for both halves of exec
+        if constexpr (TAIL) {
+          if (rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1) { mask_pair = 0x7fff7fffu; mask_last = 0x80008000u; }
+        }
+        char* ct = ybase;                                        // first column of rod group tn (uniform)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if (tn != 0) {
+            ct += 16 * ldy8;
+            asm volatile("" : "+s"(ct));
+          }
+          const size_t col = col_base4 + tn * 16;
+          const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
+          double q9[9], xb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int i = 0; i < 9; ++i) q9[i] = qe[i];
+          if constexpr (RANK1_EPI) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb[r] = q.xb[col + r];
+          }
+          static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const uint32_t row = row_base + 32 * t;
+            double gq[2][4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const double P1 = p1[t][e];
+              const double P2 = ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1);   // as strain_kernel (sri_rod.hip)
+              double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
+              if constexpr (RANK1_EPI) {
+                const double wv = q.w[row + e];
+                qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
+              }
+              if (tip_lane && t == 0 && e == 0) {
+                q.tips[col + 0] = qw; q.tips[col + 1] = qx; q.tips[col + 2] = qy; q.tips[col + 3] = qz;
+                if (monitor) {
+                  const double* old = reinterpret_cast<const double*>(side + G::QE_BYTES + G::P1_BYTES) + (wn * TN + tn) * 16 + 4 * g;
+                  const double qv[4] = {qw, qx, qy, qz};
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const double d = fabs(qv[r] - old[r]);
+                    tip_update = (d > tip_update || d != d) ? d : tip_update;       // NaN propagates as "not converged"
+                  }
+                }
+              }
+              double hk[3];                                      // K/2: halving is exact
+#pragma unroll
+              for (int a = 0; a < 3; ++a) {
+                double sacc = q9[a * 3 + 0];                     // P0 = 1
+                sacc = sacc + P1 * q9[a * 3 + 1];
+                sacc = sacc + P2 * q9[a * 3 + 2];
+                hk[a] = 0.5 * sacc;
+              }
+              quat_rhs_half(hk[0], hk[1], hk[2], qw, qx, qy, qz, gq[e]);
+            }
+            char* cb = ct;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (r != 0) {
+                cb += ldy8;
+                asm volatile("" : "+s"(cb));
+              }
+              const d2 v = pack2(gq[0][r], gq[1][r]);
+              if constexpr (TAIL && t == TM / 2 - 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("s_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, %4\n\t"
+                             "global_store_dwordx4 %0, %1, %2 offset:%3\n\t"
+                             "s_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, %5\n\t"
+                             "global_store_dwordx2 %0, %6, %2 offset:%3\n\t"
+                             "s_mov_b64 exec, -1\n\ts_nop 1"
+                             ::"v"(ylane_q), "v"(v), "s"(cb), "n"(256 * t), "s"(mask_pair), "s"(mask_last), "v"(gq[0][r]) : "memory");
+#endif
+              } else {
+                store16_sv<false, 256 * t>(cb, ylane_q, v);
+              }
+            }
+          });
+        }
+        return true;
+      }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const size_t col = col_base4 + tn * 16;
@@ -1145,7 +1244,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // other group is in the middle of its MFMAs; and the DMA pieces of both groups sit behind MFMA groups.
   // LDS hazards are those of the unshifted stream because every read of slot s-1 still precedes barrier(s).
   constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
-  constexpr int W_BOUNDARY = W_STEADY + G::NSTORE;          // ... plus one full tile's stores
+  // (the fused quaternion epilogue of an odd-row-count operator issues the last row pair as two masked instructions: TN * 4 more)
+  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0);
+  static_assert((AHEAD - 1) * G::DMA_PER_WAVE + TILE_STORES <= 63, "counted vmcnt must fit the 6-bit counter");
+  constexpr int W_BOUNDARY = W_STEADY + TILE_STORES;        // ... plus one full tile's stores
   static_assert(AHEAD == 1 || AHEAD == 2, "the wait counts assume one or two stages in flight");
   constexpr bool STAGGER = (NW >= 8) && (SRI_SCHED_HINTS != 0);
   const bool late = STAGGER && wid >= NW / 2;
