@@ -55,6 +55,7 @@ C_ABI = {
     "sri_apply_host": (_int, [_vp, _dp, _sz, _dp, _sz, _sz]),
     "sri_integrate_host": (_int, [_vp, _dp, _sz, _dp, _dp, _sz, _sz]),
     "sri_apply_set_lean_tail": (_int, [_vp, _int]),
+    "sri_apply_set_column_plan": (_int, [_vp, _int]),
     "sri_apply_set_host_copy_threads": (_int, [_vp, _int]),
     "sri_apply_set_host_memory_pinned": (_int, [_vp, _int]),
     "sri_apply_destroy": (_int, [_vp]),
@@ -382,6 +383,11 @@ class SpectralApply:
         """Odd-row-count operators: allow (default) or forbid the kernel variants that read the panel's last column up to its
         last k chunk's end where that cannot fault (``sri_apply_set_lean_tail``); same results either way."""
         _chk(load_library().sri_apply_set_lean_tail(self._h, 1 if enable else 0), "sri_apply_set_lean_tail")
+
+    def set_column_plan(self, enable: bool) -> None:
+        """Allow (default) or forbid giving the columns behind the operator's full rounds of tiles — or a small panel as a
+        whole — to a finer tile geometry of the same operator (``sri_apply_set_column_plan``); same results either way."""
+        _chk(load_library().sri_apply_set_column_plan(self._h, 1 if enable else 0), "sri_apply_set_column_plan")
 
     def set_host_copy_threads(self, threads: int) -> None:
         """CPU threads that move host panels into / out of the handle's pinned staging slots (-1 = default, 0 = caller only)."""

@@ -8,8 +8,12 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails with an error.
 #include "sri_apply_kernel.h"
 #include "sri_apply_geometries.h"
+#include "sri_column_plan.h"
 
 namespace sri {
+
+static_assert(plan::FLAT == GEO_FLAT && plan::MID == GEO_MID && plan::TALL == GEO_TALL && plan::WIDE == GEO_WIDE &&
+              plan::WIDE32 == GEO_WIDE32 && plan::TALL_STRIP == GEO_TALL_STRIP, "sri_column_plan.h uses GeoId's values");
 
 static thread_local int g_last_hip_error = 0;
 void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
@@ -92,6 +96,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->geo = rows_out <= 64 ? GEO_FLAT : ((rows_out <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
   // (tiles of one or two k chunks: the fused step needs four side buffers, which the 256-row geometry's ring leaves no room for)
   if (!square && h->geo == GEO_TALL && (rows + BK - 1) / BK < 3) h->geo = GEO_MID;
+  if (const char* v = std::getenv("SRI_APPLY_FORCE_GEO")) { if (v[0] == 'm') h->geo = GEO_MID; else if (v[0] == 'f') h->geo = GEO_FLAT; }
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
   // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant exists for
@@ -122,6 +127,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     if (h->d_w) (void)hipFree(h->d_w);
     for (sri_apply_handle::Part& part : h->parts)
       if (part.d_apack) (void)hipFree(part.d_apack);
+    for (sri_apply_handle::Alternate& alt : h->alternates)
+      if (alt.d_apack) (void)hipFree(alt.d_apack);
     delete h;
     return code;
   };
@@ -212,6 +219,38 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       h->parts_label_lean = h->parts_label + ",lean";
       h->parts_name_lean = h->parts_label_lean.c_str();
     }
+  }
+  // Alternates (sri_column_plan.h): the whole operator once more in each finer geometry — 128 x 128 and 64 x 64 tiles for a
+  // 256-row operator, 64 x 64 for a 128-row one (the 64 x 64 geometry has no ascending-k variant: not for operators that use it).
+  if (square && rows >= BK && h->geo != GEO_FLAT) {
+    const char* off = std::getenv("SRI_APPLY_COLUMN_PLAN");
+    if (off != nullptr && off[0] == '0') h->column_plan = false;
+    const double* wf = (rows % BK != 0) ? w_host : nullptr;
+    for (int geo = h->geo - 1; geo >= GEO_FLAT; --geo) {
+      if (geo == GEO_FLAT && h->ascending) break;
+      sri_apply_handle::Alternate& alt = h->alternates[h->num_alternates];
+      rc = geo == GEO_MID ? prepare_mid(device) : prepare_flat(device);
+      if (rc != SRI_OK) return fail(rc);
+      const uint32_t bm = geo == GEO_MID ? GeoMid::BM : GeoFlat::BM;
+      alt.geo = geo;
+      alt.row_blocks = (rows + bm - 1) / bm;
+      std::vector<double> pk;
+      try {
+        if (geo == GEO_MID) pack_mid(A, lda, rows, rows, h->nk, alt.row_blocks, wf, h->ascending, pk);
+        else pack_flat(A, lda, rows, rows, h->nk, alt.row_blocks, wf, false, pk);
+      } catch (const std::bad_alloc&) {
+        return fail(SRI_ENOMEM);
+      }
+      if (hipMalloc(&alt.d_apack, pk.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
+      ++h->num_alternates;                                         // (counted once it owns memory: fail() frees by pointer anyway)
+      if (hipMemcpy(alt.d_apack, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
+    }
+    for (int l = 0; l < 2; ++l)
+      for (int a = 0; a < h->num_alternates; ++a) {
+        const std::string primary = h->num_parts != 0 ? (l ? h->parts_label_lean : h->parts_label)
+                                                      : std::string(kernel_name(h->geo, true, false, l != 0));
+        h->mixed_labels[l][a] = primary + (h->alternates[a].geo == GEO_MID ? "|<128x128,dma>" : "|<64x64,dma>");
+      }
   }
   if (w_host != nullptr) {
     size_t padded = static_cast<size_t>(h->row_blocks) * h->bm;
@@ -306,40 +345,93 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // registers and 1.6 % on identical work (round 4: profiles/r04_ab_tail_lean.log).  Memory protection is page-granular (4 KiB at
   // least): if the bytes past the end lie in the SAME page as the panel's last valid byte they can be read, whatever they hold
   // (tail_fix_fast overwrites their LDS image before any MFMA sees it) — then, and only then, the LEAN twin runs (same bits).
-  bool lean = false;
-  if (dma && args.tail_k != 0 && many == nullptr) {
+  const bool may_lean = dma && args.tail_k != 0 && many == nullptr && h->lean_tail;
+  // columns [col0, col0 + cols) of the panel: may their launch take the lean twin?
+  auto lean_for = [&](size_t col0, size_t cols) {
+    if (!may_lean) return false;
+    if (col0 + cols < M) return true;                               // (the bytes behind an interior column are the panel's own)
     const uintptr_t end = reinterpret_cast<uintptr_t>(dX + (M - 1) * ldx + h->rows);      // one past the last valid byte
     const uintptr_t over = (16u - args.tail_k) * sizeof(double);
-    lean = h->lean_tail && ((end - 1) >> 12) == ((end + over - 1) >> 12);
-  }
+    return ((end - 1) >> 12) == ((end + over - 1) >> 12);
+  };
+  auto columns = [&](size_t col0, size_t cols) {                      // the launch arguments for that range of columns
+    ApplyArgs a = args;
+    if (many == nullptr) {
+      a.x = dX + col0 * ldx;
+      a.y = dY + col0 * ldy;
+      a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
+    }
+    if (d_xb != nullptr) a.xb = d_xb + col0;
+    if (d_tips != nullptr) a.tips = d_tips + col0;
+    a.m = cols;
+    return a;
+  };
   // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
-  if (h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
-      static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32)) {
-    h->last_kernel.store(lean ? h->parts_name_lean : h->parts_name, std::memory_order_relaxed);
-    for (int i = 0; i < h->num_parts; ++i) {
-      const sri_apply_handle::Part& part = h->parts[i];
-      ApplyArgs a = args;
-      a.apack = part.d_apack;
-      a.y = dY + part.row0;
-      a.w = h->d_w != nullptr ? h->d_w + part.row0 : nullptr;
-      a.rows_out = part.rows;
-      a.row_blocks = part.row_blocks;
-      a.tips = part.row0 == 0 ? d_tips : nullptr;                 // the tip node is row 0
-      a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
-      rc = part.geo == GEO_WIDE ? dispatch_wide64(h, a, rank1, stream)
-           : part.geo == GEO_WIDE32 ? dispatch_wide32(h, a, rank1, stream)
-           : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream, lean)
-                                : (part.geo == GEO_MID ? dispatch_mid(h, a, dma, rank1, stream, nullptr, lean)
-                                                       : dispatch_tall(h, a, dma, rank1, stream, nullptr, lean));
-      if (rc != SRI_OK) return rc;
+  const bool in_parts = h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
+      static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32);
+  // the operator's own path over `a.m` columns
+  auto primary = [&](const ApplyArgs& cols_args, bool lean) -> int {
+    if (in_parts) {
+      for (int i = 0; i < h->num_parts; ++i) {
+        const sri_apply_handle::Part& part = h->parts[i];
+        ApplyArgs a = cols_args;
+        a.apack = part.d_apack;
+        a.y = cols_args.y + part.row0;
+        a.w = h->d_w != nullptr ? h->d_w + part.row0 : nullptr;
+        a.rows_out = part.rows;
+        a.row_blocks = part.row_blocks;
+        a.tips = part.row0 == 0 ? cols_args.tips : nullptr;         // the tip node is row 0
+        a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
+        const int prc = part.geo == GEO_WIDE ? dispatch_wide64(h, a, rank1, stream)
+                        : part.geo == GEO_WIDE32 ? dispatch_wide32(h, a, rank1, stream)
+                        : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream, lean)
+                                             : (part.geo == GEO_MID ? dispatch_mid(h, a, dma, rank1, stream, nullptr, lean)
+                                                                    : dispatch_tall(h, a, dma, rank1, stream, nullptr, lean));
+        if (prc != SRI_OK) return prc;
+      }
+      return SRI_OK;
     }
-    return SRI_OK;
+    if (h->geo == GEO_FLAT) return dispatch_flat(h, cols_args, dma, rank1, stream, partials, false);
+    if (h->geo == GEO_MID) return dispatch_mid(h, cols_args, dma, rank1, stream, partials, lean);
+    return dispatch_tall(h, cols_args, dma, rank1, stream, partials, lean);
+  };
+
+  // Which columns go where (sri_column_plan.h): plain and rank-1 launches of a full grid only.
+  plan::Choice choice;
+  choice.primary_cols = M;
+  if (h->num_alternates != 0 && h->column_plan && dma && quat == nullptr && many == nullptr && h->max_workgroups == 0) {
+    plan::Launch own[2], finer[2];
+    int num_own = 0;
+    if (in_parts) {
+      for (int i = 0; i < h->num_parts; ++i) own[num_own++] = plan::Launch{h->parts[i].geo, h->parts[i].row_blocks};
+    } else {
+      own[num_own++] = plan::Launch{h->geo, h->row_blocks};
+    }
+    for (int a = 0; a < h->num_alternates; ++a) finer[a] = plan::Launch{h->alternates[a].geo, h->alternates[a].row_blocks};
+    choice = plan::choose(own, num_own, finer, h->num_alternates, M, h->nk, h->num_cus);
   }
-  h->last_kernel.store(kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
-  if (h->geo == GEO_FLAT) return dispatch_flat(h, args, dma, rank1, stream, partials, false);
-  if (h->geo == GEO_MID) return dispatch_mid(h, args, dma, rank1, stream, partials, lean);
-  return dispatch_tall(h, args, dma, rank1, stream, partials, lean);
+  if (choice.alt < 0) {
+    const bool lean = lean_for(0, M);
+    h->last_kernel.store(in_parts ? (lean ? h->parts_name_lean : h->parts_name)
+                                  : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
+    return primary(many == nullptr ? columns(0, M) : args, lean);
+  }
+  const sri_apply_handle::Alternate& alt = h->alternates[choice.alt];
+  const size_t kept = choice.primary_cols;
+  if (kept != 0) {
+    const bool lean = lean_for(0, kept);
+    rc = primary(columns(0, kept), lean);
+    if (rc != SRI_OK) return rc;
+    h->last_kernel.store(h->mixed_labels[lean ? 1 : 0][choice.alt].c_str(), std::memory_order_relaxed);
+  }
+  ApplyArgs rest = columns(kept, M - kept);
+  rest.apack = alt.d_apack;
+  rest.row_blocks = alt.row_blocks;
+  const bool rest_lean = lean_for(kept, M - kept) && alt.geo != GEO_FLAT;
+  if (kept == 0) h->last_kernel.store(kernel_name(alt.geo, true, false, rest_lean), std::memory_order_relaxed);
+  return alt.geo == GEO_MID ? dispatch_mid(h, rest, dma, rank1, stream, nullptr, rest_lean)
+                            : dispatch_flat(h, rest, dma, rank1, stream, nullptr, false);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
@@ -432,6 +524,12 @@ int sri_apply_set_lean_tail(sri_apply_t* h, int enable) {
   return SRI_OK;
 }
 
+int sri_apply_set_column_plan(sri_apply_t* h, int enable) {
+  if (h == nullptr) return SRI_EINVAL;
+  h->column_plan = enable != 0;
+  return SRI_OK;
+}
+
 int sri_apply_dim(const sri_apply_t* h, uint32_t* rows) {
   if (h == nullptr || rows == nullptr) return SRI_EINVAL;
   *rows = h->rows;
@@ -476,6 +574,8 @@ int sri_apply_destroy(sri_apply_t* h) {
   if (h->d_w) (void)hipFree(h->d_w);
   for (sri_apply_handle::Part& part : h->parts)
     if (part.d_apack) (void)hipFree(part.d_apack);
+  for (sri_apply_handle::Alternate& alt : h->alternates)
+    if (alt.d_apack) (void)hipFree(alt.d_apack);
   sri::host_pipe_destroy(h->pipe);   // sri_host_panels.hip
   delete h;
   return SRI_OK;

@@ -1,0 +1,128 @@
+// sri_column_plan.h — which tile geometry takes which columns of a panel (pure C++, no HIP: tests/cpp/column_plan_check.cpp)
+//
+// Every launch of sri::apply_kernel is persistent: as many workgroups as the chip keeps resident, each walking its share of
+// the tiles.  A launch therefore costs WHOLE rounds of tiles — 1.1 rounds of 256 x 128 tiles take as long as 2 — and a panel
+// of a few thousand columns leaves most CUs idle for a whole tile time (measured, N = 256: 4 096 columns take 61.7 us in
+// 256 x 128 tiles, 34.0 us in 128 x 128 tiles and 13.2 us in 64 x 64 tiles; 49 152 columns 128.5 / 124.7 / 101.4 us:
+// profiles/r04_geometry_by_columns.log).  The smaller geometries cost 10-15 % of efficiency on full rounds but their rounds
+// are short.  So a launch is planned per call: the operator's own ("primary") geometry takes the columns of its full rounds,
+// one of the finer geometries of the same operator ("alternates": every output element is the same chain of fused
+// multiply-adds in the same k order, so the results are the same bits) takes the rest — or everything, for a small panel.
+//
+// The plan comes from a cost model, not from a search on the device: time of a launch = full rounds x t(resident workgroups
+// per CU) + t(workgroups per CU in the last round) + a launch overhead, t = microseconds per 16-k chunk from the table below
+// (measured at N = 256 / 320, MI355X, round 4).  It only has to rank candidates whose times differ by more than its own
+// error: a candidate replaces "everything in the primary geometry" only if the model sees at least 5 % and 3 us to win.
+#ifndef SRI_COLUMN_PLAN_H
+#define SRI_COLUMN_PLAN_H
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+namespace sri {
+namespace plan {
+
+// ids as sri::GeoId (sri_apply_kernel.h)
+enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, GEO_COUNT = 6 };
+
+struct GeoModel {
+  int bn;            // columns per tile
+  int per_cu;        // resident workgroups per CU
+  double us[5];      // one round: microseconds per k chunk of a tile with 1 .. per_cu workgroups sharing the CU
+  double stream_us;  // several rounds: microseconds per k chunk and tile of a CU's share (workgroups out of phase overlap their tile ends)
+};
+
+inline const GeoModel& model(int geo) {
+  static const GeoModel table[GEO_COUNT] = {
+      /* FLAT   64 x 64  */ {64, 5, {0.65, 1.10, 1.80, 2.80, 2.90}, 0.52},
+      /* MID   128 x 128 */ {128, 2, {2.00, 4.20, 0, 0, 0}, 2.10},
+      /* TALL  256 x 128 */ {128, 1, {3.90, 0, 0, 0, 0}, 3.90},
+      /* WIDE   64 x 256 */ {256, 2, {2.10, 3.90, 0, 0, 0}, 1.95},
+      /* WIDE32 32 x 256 */ {256, 2, {1.30, 2.30, 0, 0, 0}, 1.15},
+      /* STRIP 272 x 128 */ {128, 1, {4.30, 0, 0, 0, 0}, 4.30},
+  };
+  return table[geo];
+}
+
+constexpr double kLaunchOverheadUs = 3.5;
+
+struct Launch {
+  int geo = TALL;
+  uint32_t row_blocks = 1;
+};
+
+// one persistent launch of `l` over `cols` columns (0 columns: no launch)
+inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
+  if (cols == 0) return 0.0;
+  const GeoModel& g = model(l.geo);
+  const double tiles = std::ceil(static_cast<double>(cols) / g.bn) * l.row_blocks;
+  const double slots = static_cast<double>(cus) * g.per_cu;
+  double t;
+  if (tiles <= slots) {
+    // one round: the grid is the tiles and the hardware spreads it over the CUs
+    t = g.us[static_cast<int>(std::ceil(tiles / cus)) - 1];
+  } else if (g.per_cu > 2) {
+    // many small workgroups per CU: the CU works through its share of the tiles like a queue (measured: 3 072 tiles of 64 x 64
+    // take 101 us where 3 rounds of 5 per CU would take 130)
+    t = std::ceil(tiles / cus) * g.stream_us;
+  } else {
+    // whole rounds; the tiles behind the last full round go to the FIRST workgroups of a grid that sits per_cu to a CU
+    // (measured: 768 tiles of 128 x 128 take 125 us, nearly two full rounds)
+    const double full = std::floor(tiles / slots);
+    const double rem = tiles - full * slots;
+    t = full * g.us[g.per_cu - 1];
+    if (rem > 0.0) {
+      int share = static_cast<int>(std::ceil(rem * g.per_cu / cus));
+      if (share > g.per_cu) share = g.per_cu;
+      t += g.us[share - 1];
+    }
+  }
+  return t * nk + kLaunchOverheadUs;
+}
+
+struct Choice {
+  size_t primary_cols = 0;   // columns [0, primary_cols) go to the operator's own launches ...
+  int alt = -1;              // ... the rest to alternates[alt] (-1: there is no rest)
+  double model_us = 0.0;     // what the model expects of this choice
+  double primary_only_us = 0.0;
+};
+
+// `primary`: the launches the operator's own path makes over its columns (one, or two for an operator in parts);
+// `alternates`: finer geometries of the WHOLE operator.  `round_cols`: the columns of one full round of primary[0].
+inline Choice choose(const Launch* primary, int num_primary, const Launch* alternates, int num_alternates, size_t M, uint32_t nk, int cus) {
+  auto primary_us = [&](size_t cols) {
+    double t = 0.0;
+    for (int i = 0; i < num_primary; ++i) t += launch_us(primary[i], cols, nk, cus);
+    return t;
+  };
+  Choice best;
+  best.primary_cols = M;
+  best.alt = -1;
+  best.model_us = best.primary_only_us = primary_us(M);
+  if (M == 0 || num_alternates == 0) return best;
+  const GeoModel& g0 = model(primary[0].geo);
+  // columns of a full round of the first (dominant) primary launch, in whole tiles of the widest primary tile (256)
+  size_t round_cols = static_cast<size_t>(cus) * g0.per_cu / primary[0].row_blocks * g0.bn;
+  round_cols -= round_cols % 256;
+  Choice cand = best;
+  for (int a = 0; a < num_alternates; ++a) {
+    size_t keeps[2] = {0, round_cols != 0 ? M / round_cols * round_cols : 0};
+    for (size_t keep : keeps) {
+      if (keep >= M) continue;
+      const double t = primary_us(keep) + launch_us(alternates[a], M - keep, nk, cus);
+      if (t < cand.model_us) {
+        cand.primary_cols = keep;
+        cand.alt = a;
+        cand.model_us = t;
+      }
+    }
+  }
+  if (cand.alt >= 0 && cand.model_us <= 0.95 * best.model_us && cand.model_us + 3.0 <= best.model_us) return cand;
+  return best;
+}
+
+}  // namespace plan
+}  // namespace sri
+
+#endif  // SRI_COLUMN_PLAN_H

@@ -147,6 +147,17 @@ struct sri_apply_handle {
   const char* parts_name = "none";
   std::string parts_label_lean;
   const char* parts_name_lean = "none";
+  // Alternates (sri_column_plan.h): the WHOLE operator packed once more for each finer tile geometry; run() gives them the
+  // columns behind the primary path's full rounds of tiles, or a small panel as a whole.  Same k order, same bits.
+  struct Alternate {
+    int geo = -1;
+    uint32_t row_blocks = 0;
+    double* d_apack = nullptr;
+  };
+  Alternate alternates[2];
+  int num_alternates = 0;
+  bool column_plan = true;           // sri_apply_set_column_plan; SRI_APPLY_COLUMN_PLAN=0 in the environment at creation: off
+  std::string mixed_labels[2][2];    // [primary lean][alternate]: what sri_apply_last_kernel reports for a primary + alternate launch
   bool lean_tail = true;             // odd-row-count operators: take the lean kernels where run() finds them safe (sri_apply_set_lean_tail)
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use

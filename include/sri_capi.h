@@ -184,6 +184,17 @@ int sri_apply_set_host_memory_pinned(sri_apply_t *h, int pinned);
  * enable == 0, the variant that never reads past the panel.  Same results bit for bit. */
 int sri_apply_set_lean_tail(sri_apply_t *h, int enable);
 
+/* Launch policy of operators of more than 64 rows: which tile geometry takes which columns of a panel.  Every launch walks
+ * whole rounds of tiles over the chip, so a panel of 1.1 rounds of 256 x 128 tiles costs 2, and one of a few thousand columns
+ * leaves most of the chip idle for a whole tile time.  enable != 0 (default; SRI_APPLY_COLUMN_PLAN=0 in the environment at
+ * creation turns it off): per call, the operator's own geometry takes the columns of its full rounds and a finer geometry of the
+ * same operator (128 x 128 or 64 x 64 tiles) the rest — or all of a small panel — wherever a cost model built from measured
+ * tile times expects at least 5 % to win (csrc/sri_column_plan.h; e.g. N = 256, 4 096 columns: 61.7 -> 13.2 us).  The extra
+ * launches go to `stream` one after the other.  enable == 0: always the operator's own geometry.  Same results bit for bit
+ * (same k order, same chain of fused multiply-adds per output element).  Plain applies and sri_integrate; the fused step,
+ * sri_apply_many and handles with a workgroup cap (sri_apply_set_max_workgroups) keep one geometry. */
+int sri_apply_set_column_plan(sri_apply_t *h, int enable);
+
 int sri_apply_destroy(sri_apply_t *h);
 
 /* ---------------------------------------------------------------------------------------- */

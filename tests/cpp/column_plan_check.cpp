@@ -1,0 +1,87 @@
+// column_plan_check.cpp — csrc/sri_column_plan.h on the CPU: the choices it makes at the sizes that were measured on the
+// MI355X (profiles/r04_geometry_by_columns.log), and the invariants run() relies on for every size.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "sri_column_plan.h"
+
+using namespace sri::plan;
+
+static int failures = 0;
+#define CHECK(cond, ...)                                      \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      ++failures;                                             \
+      std::printf("FAILED %s:%d: %s  ", __FILE__, __LINE__, #cond); \
+      std::printf(__VA_ARGS__);                               \
+      std::printf("\n");                                      \
+    }                                                         \
+  } while (0)
+
+int main() {
+  const int cus = 256;
+  // ---- N = 256 (one 256-row block, 16 chunks): alternates 128 x 128 (2 row blocks) and 64 x 64 (4 row blocks)
+  const Launch tall{TALL, 1};
+  const Launch finer[2] = {{MID, 2}, {FLAT, 4}};
+  struct Expect { size_t cols; size_t kept; int alt; };
+  const Expect table[] = {
+      {4096, 0, 1},          // 32 tall tiles: measured 61.7 / 34.0 / 13.2 us -> all in 64 x 64 tiles
+      {8192, 0, 1},          // 61.9 / 35.4 / 20.3
+      {16384, 0, 0},         // 64.2 / 38.6 / 49.5 -> 128 x 128
+      {32768, 32768, -1},    // one full round: 70.8 / 69.2 / 73.7 -> stays
+      {262144, 262144, -1},  // the BASELINE panel: 8 full rounds
+      {49152, 32768, 0},     // 1.5 rounds: one round tall + the rest finer (measured whole: 128.5 / 124.7 / 101.4)
+  };
+  for (const Expect& e : table) {
+    const Choice c = choose(&tall, 1, finer, 2, e.cols, 16, cus);
+    CHECK(c.primary_cols == e.kept && c.alt == e.alt, "cols %zu: kept %zu alt %d (model %.1f us, primary only %.1f us)", e.cols,
+          c.primary_cols, c.alt, c.model_us, c.primary_only_us);
+  }
+  // the model against the measurements it was fitted to (within 15 %)
+  struct Timed { Launch l; size_t cols; double us; };
+  const Timed timed[] = {{{TALL, 1}, 4096, 61.7},  {{MID, 2}, 4096, 34.0},   {{FLAT, 4}, 4096, 13.2},  {{FLAT, 4}, 8192, 20.3},
+                         {{MID, 2}, 16384, 38.6},  {{FLAT, 4}, 16384, 49.5}, {{TALL, 1}, 32768, 70.8}, {{MID, 2}, 32768, 69.2},
+                         {{TALL, 1}, 49152, 128.5}, {{FLAT, 4}, 49152, 101.4}, {{TALL, 1}, 262144, 498.2}};
+  for (const Timed& t : timed) {
+    const double m = launch_us(t.l, t.cols, 16, cus);
+    CHECK(m > 0.85 * t.us && m < 1.15 * t.us, "geo %d cols %zu: model %.1f us, measured %.1f us", t.l.geo, t.cols, m, t.us);
+  }
+  // ---- N = 320 in parts (256-row main part + 64 x 256 last part, 20 chunks), alternates of the whole operator
+  {
+    const Launch own[2] = {{TALL, 1}, {WIDE, 1}};
+    const Launch alt[2] = {{MID, 3}, {FLAT, 5}};
+    const double whole = launch_us(own[0], 209664, 20, cus) + launch_us(own[1], 209664, 20, cus);
+    CHECK(whole > 0.9 * 702.7 && whole < 1.1 * 702.7, "N = 320 sweep panel: model %.1f us, measured 702.7 us", whole);
+    const Choice c = choose(own, 2, alt, 2, 209664, 20, cus);
+    CHECK(c.alt < 0 || (c.primary_cols % 256 == 0 && c.primary_cols < 209664), "kept %zu", c.primary_cols);
+  }
+  // ---- invariants, random shapes
+  std::mt19937_64 rng(12345);
+  for (int it = 0; it < 200000; ++it) {
+    const uint32_t rows = 65 + rng() % 2000;
+    const uint32_t nk = (rows + 15) / 16;
+    Launch own[2];
+    int num_own = 1;
+    const int base = rng() % 2 ? TALL : MID;
+    const uint32_t bm = base == TALL ? 256 : 128;
+    own[0] = Launch{base, (rows + bm - 1) / bm};
+    if (rng() % 3 == 0) own[num_own++] = Launch{static_cast<int>(rng() % 2 ? WIDE : WIDE32), 1};
+    Launch alt[2];
+    int num_alt = 0;
+    if (base == TALL) alt[num_alt++] = Launch{MID, (rows + 127) / 128};
+    if (rng() % 4 != 0) alt[num_alt++] = Launch{FLAT, (rows + 63) / 64};
+    const size_t M = 1 + rng() % (rng() % 2 ? 5000 : 600000);
+    const Choice c = choose(own, num_own, alt, num_alt, M, nk, cus);
+    CHECK(c.primary_cols <= M, "kept %zu of %zu", c.primary_cols, M);
+    CHECK((c.alt < 0) == (c.primary_cols == M), "alt %d kept %zu of %zu", c.alt, c.primary_cols, M);
+    CHECK(c.alt < num_alt, "alt %d of %d", c.alt, num_alt);
+    CHECK(c.primary_cols == M || c.primary_cols % 256 == 0, "kept %zu: whole tiles of every primary geometry", c.primary_cols);
+    CHECK(c.model_us <= c.primary_only_us, "model %.2f > primary only %.2f", c.model_us, c.primary_only_us);
+    if (c.alt >= 0) CHECK(c.model_us <= 0.95 * c.primary_only_us, "deviates for %.2f against %.2f", c.model_us, c.primary_only_us);
+    const Choice none = choose(own, num_own, alt, 0, M, nk, cus);
+    CHECK(none.alt < 0 && none.primary_cols == M, "no alternates: nothing to choose");
+  }
+  std::printf("column_plan_check: %d failures\n", failures);
+  return failures == 0 ? 0 : 1;
+}

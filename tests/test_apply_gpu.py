@@ -54,7 +54,8 @@ def _operator_matrix(oracle, n, which):
     (1024, 1, 64),
 ])
 @pytest.mark.parametrize("kind", ["uniform", "rod"])
-def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
+@pytest.mark.parametrize("planned", [False, True])     # the operator's own tile geometry / whatever the column plan picks for M columns
+def test_apply_matches_oracle(sri, oracle, n, which, M, kind, planned):
     A = _operator_matrix(oracle, n, which)
     rows = A.shape[0]
     if kind == "uniform":
@@ -63,6 +64,7 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind):
         X = rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M]
         X = np.asfortranarray(X)
     op = sri.SpectralApply(n, which)
+    op.set_column_plan(planned)
     assert op.rows == rows
     Y = _run(op, X)
     assert op.ascending_k == (rows > 512 and which != 1)
@@ -110,6 +112,7 @@ def test_geometry_above_256_rows(sri, oracle, n, which, M, geometry):
     rows = A.shape[0]
     X = np.asfortranarray(rod_strain_panel(n, (M + 3) // 4, rows=rows)[:, :M])
     op = sri.SpectralApply(n, which)
+    op.set_column_plan(False)        # (these panels are a fraction of a round of tiles: the plan would hand them to 64 x 64 tiles)
     Y = _run(op, X)
     assert geometry in op.last_kernel.replace(",lean", ""), op.last_kernel      # (",lean": which twin of an odd-row-count kernel ran)
     assert op.ascending_k == (rows > 512 and which != 1)
@@ -125,8 +128,10 @@ def test_mfma_layout_exact_integers(sri):
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
-        Y = _run(op, X)
-        assert np.array_equal(Y, A @ X), (rows, M, op.last_kernel)
+        for planned in (False, True):
+            op.set_column_plan(planned)
+            Y = _run(op, X)
+            assert np.array_equal(Y, A @ X), (rows, M, op.last_kernel)
 
 
 def test_unaligned_and_strided_panels(sri, oracle):
@@ -223,6 +228,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             os.environ["SRI_APPLY_NO_PARTS"] = env
             try:
                 ops.append(sri.SpectralApply(n, which))
+                ops[-1].set_column_plan(False)
             finally:
                 del os.environ["SRI_APPLY_NO_PARTS"]
         ld = rows + ld_extra
@@ -257,6 +263,7 @@ def test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides(sri):
     lib = sri.load_library()
     for n, which, M in [(256, 1, 3000), (1024, 2, 600), (300, 0, 1500), (258, 1, 1111), (128, 1, 5000)]:
         op = sri.SpectralApply(n, which)
+        op.set_column_plan(False)
         rows = op.rows
         over = (16 - rows % 16) * 8
         pool = torch.zeros(rows * M + 4096, dtype=torch.float64, device="cuda")
@@ -288,6 +295,49 @@ def test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides(sri):
         assert lib.sri_apply(op._h, Xm.data_ptr(), rows, Yd.data_ptr(), rows, M, None) == 0
         torch.cuda.synchronize()
         assert torch.equal(Yd, Ym)
+
+
+def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
+    """csrc/sri_column_plan.h: per call, the operator's own tile geometry takes the columns of its full rounds of tiles and a
+    finer geometry of the same operator the rest — or all of a small panel.  Against the same handle with the plan switched off:
+    Y, the tip row and sri_integrate's result bit for bit, the padding rows of a strided panel untouched — for plans that keep
+    nothing, plans in two geometries ("|" in the reported kernel), operators in parts, with a strip, with a k tail (where the
+    kept columns always take the lean kernel: the bytes behind their last column are the panel's own), in ascending k order."""
+    import torch
+
+    lib = sri.load_library()
+    for n, which, M, ld_extra, mark in [(256, 0, 40000, 0, "<256x128,dma>|<64x64,dma>"), (256, 1, 40000, 1, "<256x128,dma,lean>|<64x64,dma>"),
+                                        (256, 1, 49152, 0, "<256x128,dma,lean>|<128x128,dma>"), (256, 0, 16384, 3, "f64<128x128,dma>"),
+                                        (256, 1, 3000, 0, "f64<64x64,dma>"), (320, 0, 40000, 0, "<256x128,dma>+<64x256,dma>|<64x64,dma>"),
+                                        (300, 1, 36001, 2, "|<64x64,dma>"), (257, 0, 40000, 3, "<256+16x128,dma>,lean|<64x64,dma>"),
+                                        (512, 0, 40000, 0, "<256x128,dma>|<128x128,dma>"), (1024, 0, 4096, 0, "f64<128x128,dma>"),
+                                        (1023, 2, 1000, 1, "f64<128x128,dma"), (128, 0, 16384, 0, "f64<64x64,dma>"), (384, 0, 100000, 0, "<128x128,dma>|<64x64,dma>")]:
+        op = sri.SpectralApply(n, which)
+        rows = op.rows
+        ld = rows + ld_extra
+        Xd = torch.full((M, ld), float("nan"), dtype=torch.float64, device="cuda")
+        Xd[:, :rows] = torch.rand((M, rows), dtype=torch.float64, device="cuda") * 2 - 1
+        outs = []
+        for planned in (False, True):
+            op.set_column_plan(planned)
+            Yd = torch.full((M, ld), -7.25, dtype=torch.float64, device="cuda")
+            tips = torch.zeros(M, dtype=torch.float64, device="cuda")
+            assert lib.sri_apply_tips(op._h, Xd.data_ptr(), ld, Yd.data_ptr(), ld, M, tips.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
+            outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
+        assert mark in outs[1][2] and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which, M, outs[1][2])
+        assert torch.equal(outs[1][1], outs[1][0][:, 0])
+        if which == 1:
+            xb = torch.rand(M, dtype=torch.float64, device="cuda")
+            B = Xd[:, :rows].contiguous()
+            ys = []
+            for planned in (False, True):
+                op.set_column_plan(planned)
+                ys.append(op.integrate(B, xb))
+            assert torch.equal(ys[0], ys[1]), (n, M, "integrate", op.last_kernel)
+        del Xd, outs
 
 
 @pytest.mark.parametrize("n", [16, 64, 256, 300, 321])
@@ -333,12 +383,14 @@ def test_apply_tips_is_row0_of_the_result(sri, n, which, M):
 
     op = sri.SpectralApply(n, which)
     X = torch.rand((M, op.rows), dtype=torch.float64, device="cuda") * 2 - 1
-    tips = torch.full((M,), 7.0, dtype=torch.float64, device="cuda")
-    Y = op.apply(X, tips=tips)
-    Y2 = op.apply(X)
-    torch.cuda.synchronize()
-    assert torch.equal(Y, Y2)
-    assert torch.equal(tips, Y[:, 0].contiguous())
+    for planned in (False, True):
+        op.set_column_plan(planned)
+        tips = torch.full((M,), 7.0, dtype=torch.float64, device="cuda")
+        Y = op.apply(X, tips=tips)
+        Y2 = op.apply(X)
+        torch.cuda.synchronize()
+        assert torch.equal(Y, Y2)
+        assert torch.equal(tips, Y[:, 0].contiguous())
     with pytest.raises(ValueError):
         op.apply(X, tips=tips[:-1])
 
@@ -347,26 +399,30 @@ def test_apply_is_graph_capturable(sri):
     """sri_apply only enqueues a kernel (no allocation, attribute call or sync): capture it in a HIP graph."""
     import torch
 
-    n, M = 256, 4096
+    n = 256
     op = sri.SpectralApply(n, 0)
-    X = torch.rand((M, n), dtype=torch.float64, device="cuda") * 2 - 1
-    Y = torch.zeros_like(X)
-    ref = op.apply(X)                                  # eager result
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
-            op.apply(X, out=Y)
-    Y.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(Y, ref)
-    X.mul_(0.5)                                        # same buffers, new contents: replay must recompute
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(Y, op.apply(X))
+    # own geometry; the column plan's choice for a small panel (64 x 64 tiles); a planned launch in two geometries (two kernels)
+    for M, planned, mark in ((4096, False, "<256x128,dma>"), (4096, True, "<64x64,dma>"), (40000, True, "|")):
+        op.set_column_plan(planned)
+        X = torch.rand((M, n), dtype=torch.float64, device="cuda") * 2 - 1
+        Y = torch.zeros_like(X)
+        ref = op.apply(X)                                  # eager result
+        assert mark in op.last_kernel, (M, planned, op.last_kernel)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                op.apply(X, out=Y)
+        Y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Y, ref)
+        X.mul_(0.5)                                        # same buffers, new contents: replay must recompute
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Y, op.apply(X))
 
 
 def test_apply_host_roundtrip(sri, oracle):
@@ -437,14 +493,16 @@ def test_full_config5_n1024(sri, oracle, kind):
     _full_size_checks(sri, oracle, 1024, 8192, kind)
 
 
-@pytest.mark.parametrize("n,which,M", [(256, 0, 20000), (256, 1, 9001), (1024, 0, 2000), (64, 0, 50000), (128, 0, 7000)])
-def test_repeated_launches_are_bit_identical(sri, n, which, M):
+@pytest.mark.parametrize("n,which,M,planned", [(256, 0, 20000, False), (256, 1, 9001, False), (1024, 0, 2000, False), (64, 0, 50000, True),
+                                               (128, 0, 7000, False), (256, 0, 40000, True), (256, 1, 9001, True), (300, 1, 50000, True)])
+def test_repeated_launches_are_bit_identical(sri, n, which, M, planned):
     """The kernel synchronises its LDS ring by hand (counted vmcnt + raw barriers, shifted wave groups): a
     race or a read of a not-yet-landed stage would show up as run-to-run differences.  Thirty launches of the
     same apply, interleaved with an unrelated memory-heavy kernel, must agree bit for bit."""
     import torch
 
     op = sri.SpectralApply(n, which)
+    op.set_column_plan(planned)
     g = torch.Generator(device="cuda").manual_seed(5)
     X = torch.rand((M, op.rows), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     ref = op.apply(X).clone()

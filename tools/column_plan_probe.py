@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""The column plan (csrc/sri_column_plan.h) against "always the operator's own geometry": time per launch and the bits.
+
+    python tools/column_plan_probe.py [--cases n:columns[:operator] ...] [--rounds 5] [--reps 100]
+
+One process, interleaved rounds; per case the min / median time per launch with the plan off and on, the kernels that ran,
+and whether the two outputs are the same bits.  Default cases: N = 256 / 255 rows / 320 / 512 / 1024 at panel sizes between
+a fraction of a round of tiles and several rounds plus a fraction."""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", nargs="*", default=[])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=100)
+    a = ap.parse_args()
+    import torch
+    import experimental_gpu_programming_for_a_spectral_numerical_integration_amd as sri
+
+    cases = []
+    for c in a.cases:
+        f = [int(v) for v in c.split(":")]
+        cases.append((f[0], f[1], f[2] if len(f) > 2 else 0))
+    if not cases:
+        for n, which in ((256, 0), (256, 1), (320, 0), (512, 0), (1024, 0), (128, 0), (384, 0), (257, 0)):
+            for cols in (1024, 4096, 16384, 40000, 49152, 100000, 200000, 262144 + 4096):
+                if n * cols * 8 <= 2 ** 31:
+                    cases.append((n, cols, which))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    warm = sri.SpectralApply(256, 0)
+    Xw = torch.randn(4096, 256, dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.5:                     # clock ramp
+        for _ in range(20):
+            warm.apply(Xw)
+        torch.cuda.synchronize()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    for n, cols, which in cases:
+        op = sri.SpectralApply(n, which)
+        rows = op.rows
+        X = torch.randn(cols, rows, dtype=torch.float64, device=dev, generator=gen)
+        modes = (False, True)
+        Ys = {m: torch.empty_like(X) for m in modes}
+        times = {m: [] for m in modes}
+        names = {}
+        reps = max(10, min(a.reps, int(2e5 / max(1.0, 2e-6 * rows * rows * cols / 60.0))))
+        for _ in range(a.rounds):
+            for m in modes:
+                op.set_column_plan(m)
+                for _ in range(5):
+                    op.apply(X, out=Ys[m])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    op.apply(X, out=Ys[m])
+                e1.record()
+                torch.cuda.synchronize()
+                times[m].append(e0.elapsed_time(e1) / reps * 1e3)
+                names[m] = op.last_kernel
+        flops = 2.0 * rows * rows * cols
+        same = torch.equal(Ys[False], Ys[True])
+        t_off, t_on = min(times[False]), min(times[True])
+        print(f"N={n} op={which} cols={cols:7d}  own {t_off:8.1f} us ({flops / t_off / 1e6 / 78.6:.3f})  planned {t_on:8.1f} us "
+              f"({flops / t_on / 1e6 / 78.6:.3f})  x{t_off / t_on:.3f}  same bits {same}  {names[True].replace('sri_apply_mfma_f64', '')}"
+              f"  [own: {names[False].replace('sri_apply_mfma_f64', '')}]", flush=True)
+        del op, X, Ys
+
+
+if __name__ == "__main__":
+    main()
