@@ -65,6 +65,7 @@ C_ABI = {
     "sri_rod_quaternion_rhs": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_set_resident": (_int, [_vp, _int]),
     "sri_rod_set_predictor": (_int, [_vp, _int]),
+    "sri_rod_last_apply_kernel": (C.c_char_p, [_vp]),
     "sri_rod_quaternion_step": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sri_rod_position_rhs": (_int, [_vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "sri_rod_integrate_quaternions": (_int, [_vp, _vp, _sz, _dp, _vp, _sz, _dbl, _u32, C.POINTER(_u32), _dp, _vp]),
@@ -456,6 +457,11 @@ class RodIntegrator:
         N > 64; inside the one-launch pipeline a 32-node one for 32 < N <= 64 and a 16-node one for 16 < N <= 32.  False starts
         from q_init."""
         _chk(load_library().sri_rod_set_predictor(self._h, 1 if enable else 0), "sri_rod_set_predictor")
+
+    @property
+    def last_apply_kernel(self) -> str:
+        """What the handle's integration operator launched last (``sri_rod_last_apply_kernel``): a fused step or a plain apply."""
+        return load_library().sri_rod_last_apply_kernel(self._h).decode()
 
     def _check_qe(self, qe):
         import torch

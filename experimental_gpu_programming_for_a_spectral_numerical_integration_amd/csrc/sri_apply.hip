@@ -397,10 +397,11 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     return dispatch_tall(h, cols_args, dma, rank1, stream, partials, lean);
   };
 
-  // Which columns go where (sri_column_plan.h): plain and rank-1 launches of a full grid only.
+  // Which columns go where (sri_column_plan.h): launches of a full grid on one panel.  The fused step keeps ONE geometry per launch
+  // (its convergence monitors belong to the workgroups of one grid) — its own, or a finer one for all columns of a small batch.
   plan::Choice choice;
   choice.primary_cols = M;
-  if (h->num_alternates != 0 && h->column_plan && dma && quat == nullptr && many == nullptr && h->max_workgroups == 0) {
+  if (h->num_alternates != 0 && h->column_plan && dma && many == nullptr && h->max_workgroups == 0) {
     plan::Launch own[2], finer[2];
     int num_own = 0;
     if (in_parts) {
@@ -409,7 +410,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       own[num_own++] = plan::Launch{h->geo, h->row_blocks};
     }
     for (int a = 0; a < h->num_alternates; ++a) finer[a] = plan::Launch{h->alternates[a].geo, h->alternates[a].row_blocks};
-    choice = plan::choose(own, num_own, finer, h->num_alternates, M, h->nk, h->num_cus);
+    choice = plan::choose(own, num_own, finer, h->num_alternates, M, h->nk, h->num_cus, quat == nullptr);
   }
   if (choice.alt < 0) {
     const bool lean = lean_for(0, M);
@@ -429,9 +430,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   rest.apack = alt.d_apack;
   rest.row_blocks = alt.row_blocks;
   const bool rest_lean = lean_for(kept, M - kept) && alt.geo != GEO_FLAT;
-  if (kept == 0) h->last_kernel.store(kernel_name(alt.geo, true, false, rest_lean), std::memory_order_relaxed);
-  return alt.geo == GEO_MID ? dispatch_mid(h, rest, dma, rank1, stream, nullptr, rest_lean)
-                            : dispatch_flat(h, rest, dma, rank1, stream, nullptr, false);
+  if (kept == 0) h->last_kernel.store(kernel_name(alt.geo, true, quat != nullptr, rest_lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
+  return alt.geo == GEO_MID ? dispatch_mid(h, rest, dma, rank1, stream, partials, rest_lean)
+                            : dispatch_flat(h, rest, dma, rank1, stream, partials, false);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,

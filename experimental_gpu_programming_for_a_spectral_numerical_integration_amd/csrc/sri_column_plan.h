@@ -9,10 +9,12 @@
 // one of the finer geometries of the same operator ("alternates": every output element is the same chain of fused
 // multiply-adds in the same k order, so the results are the same bits) takes the rest — or everything, for a small panel.
 //
-// The plan comes from a cost model, not from a search on the device: time of a launch = full rounds x t(resident workgroups
-// per CU) + t(workgroups per CU in the last round) + a launch overhead, t = microseconds per 16-k chunk from the table below
-// (measured at N = 256 / 320, MI355X, round 4).  It only has to rank candidates whose times differ by more than its own
-// error: a candidate replaces "everything in the primary geometry" only if the model sees at least 5 % and 3 us to win.
+// The plan comes from a cost model, not from a search on the device (launch_us() below): a launch of at most one round takes
+// t(workgroups sharing a CU) per 16-k chunk; several rounds of the large geometries take whole rounds, the last one as full as
+// its tiles make it; the 64 x 64 geometry, five workgroups to a CU, works through a CU's share of the tiles like a queue; plus a
+// launch overhead.  The table was measured at N = 128 ... 384 on an MI355X (round 4).  The model only has to rank candidates
+// whose times differ by more than its own error: a candidate replaces "everything in the primary geometry" only if the model
+// sees at least 5 % and 3 us to win (measured against the plan switched off: profiles/r04_column_plan_probe.log).
 #ifndef SRI_COLUMN_PLAN_H
 #define SRI_COLUMN_PLAN_H
 
@@ -31,16 +33,17 @@ struct GeoModel {
   int per_cu;        // resident workgroups per CU
   double us[5];      // one round: microseconds per k chunk of a tile with 1 .. per_cu workgroups sharing the CU
   double stream_us;  // several rounds: microseconds per k chunk and tile of a CU's share (workgroups out of phase overlap their tile ends)
+  double tile_us;    // ... plus this much per tile (N = 128 against N = 256: the tile ends do not shrink with k)
 };
 
 inline const GeoModel& model(int geo) {
   static const GeoModel table[GEO_COUNT] = {
-      /* FLAT   64 x 64  */ {64, 5, {0.65, 1.10, 1.80, 2.80, 2.90}, 0.52},
-      /* MID   128 x 128 */ {128, 2, {2.00, 4.20, 0, 0, 0}, 2.10},
-      /* TALL  256 x 128 */ {128, 1, {3.90, 0, 0, 0, 0}, 3.90},
-      /* WIDE   64 x 256 */ {256, 2, {2.10, 3.90, 0, 0, 0}, 1.95},
-      /* WIDE32 32 x 256 */ {256, 2, {1.30, 2.30, 0, 0, 0}, 1.15},
-      /* STRIP 272 x 128 */ {128, 1, {4.30, 0, 0, 0, 0}, 4.30},
+      /* FLAT   64 x 64  */ {64, 5, {0.65, 1.10, 1.80, 2.80, 2.90}, 0.48, 0.6},
+      /* MID   128 x 128 */ {128, 2, {2.00, 4.00, 0, 0, 0}, 2.00, 0.0},
+      /* TALL  256 x 128 */ {128, 1, {3.90, 0, 0, 0, 0}, 3.90, 0.0},
+      /* WIDE   64 x 256 */ {256, 2, {2.10, 3.90, 0, 0, 0}, 1.95, 0.0},
+      /* WIDE32 32 x 256 */ {256, 2, {1.30, 2.30, 0, 0, 0}, 1.15, 0.0},
+      /* STRIP 272 x 128 */ {128, 1, {4.30, 0, 0, 0, 0}, 4.30, 0.0},
   };
   return table[geo];
 }
@@ -58,7 +61,7 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
   const GeoModel& g = model(l.geo);
   const double tiles = std::ceil(static_cast<double>(cols) / g.bn) * l.row_blocks;
   const double slots = static_cast<double>(cus) * g.per_cu;
-  double t;
+  double t, per_tile = 0.0;
   if (tiles <= slots) {
     // one round: the grid is the tiles and the hardware spreads it over the CUs
     t = g.us[static_cast<int>(std::ceil(tiles / cus)) - 1];
@@ -66,6 +69,7 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
     // many small workgroups per CU: the CU works through its share of the tiles like a queue (measured: 3 072 tiles of 64 x 64
     // take 101 us where 3 rounds of 5 per CU would take 130)
     t = std::ceil(tiles / cus) * g.stream_us;
+    per_tile = std::ceil(tiles / cus) * g.tile_us;
   } else {
     // whole rounds; the tiles behind the last full round go to the FIRST workgroups of a grid that sits per_cu to a CU
     // (measured: 768 tiles of 128 x 128 take 125 us, nearly two full rounds)
@@ -78,7 +82,7 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
       t += g.us[share - 1];
     }
   }
-  return t * nk + kLaunchOverheadUs;
+  return t * nk + per_tile + kLaunchOverheadUs;
 }
 
 struct Choice {
@@ -89,8 +93,10 @@ struct Choice {
 };
 
 // `primary`: the launches the operator's own path makes over its columns (one, or two for an operator in parts);
-// `alternates`: finer geometries of the WHOLE operator.  `round_cols`: the columns of one full round of primary[0].
-inline Choice choose(const Launch* primary, int num_primary, const Launch* alternates, int num_alternates, size_t M, uint32_t nk, int cus) {
+// `alternates`: finer geometries of the WHOLE operator.  `may_split` false: one geometry for all columns (the fused step, whose
+// convergence monitors belong to the workgroups of ONE grid) — the choice is primary_cols == M or primary_cols == 0.
+inline Choice choose(const Launch* primary, int num_primary, const Launch* alternates, int num_alternates, size_t M, uint32_t nk, int cus,
+                     bool may_split = true) {
   auto primary_us = [&](size_t cols) {
     double t = 0.0;
     for (int i = 0; i < num_primary; ++i) t += launch_us(primary[i], cols, nk, cus);
@@ -107,7 +113,7 @@ inline Choice choose(const Launch* primary, int num_primary, const Launch* alter
   round_cols -= round_cols % 256;
   Choice cand = best;
   for (int a = 0; a < num_alternates; ++a) {
-    size_t keeps[2] = {0, round_cols != 0 ? M / round_cols * round_cols : 0};
+    size_t keeps[2] = {0, (may_split && round_cols != 0) ? M / round_cols * round_cols : 0};
     for (size_t keep : keeps) {
       if (keep >= M) continue;
       const double t = primary_us(keep) + launch_us(alternates[a], M - keep, nk, cus);

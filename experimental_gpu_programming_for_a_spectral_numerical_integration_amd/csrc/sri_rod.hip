@@ -442,6 +442,8 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
   return SRI_OK;
 }
 
+const char* sri_rod_last_apply_kernel(const sri_rod_t* h) { return (h != nullptr && h->integ != nullptr) ? sri_apply_last_kernel(h->integ) : "none"; }
+
 int sri_rod_set_predictor(sri_rod_t* h, int enable) {
   if (h == nullptr) return SRI_EINVAL;
   // large grids start from a 32-node solution (h->coarse), on-chip grids of more than 16 nodes from a 16-node one

@@ -310,6 +310,11 @@ const char *sri_rccl_strerror(int rccl_result);
  * (static string, e.g. "sri_apply_mfma_f64<256x64,dma>"). */
 const char *sri_apply_last_kernel(const sri_apply_t *h);
 
+/* The same for the integration operator inside a rod handle: what its last launch was — a fused quaternion step
+ * ("...,quat>"), or the plain integration that closes a solve ("none" for a solve that stayed in the one-launch on-chip
+ * pipeline). */
+const char *sri_rod_last_apply_kernel(const sri_rod_t *h);
+
 /* The order in which a launch of this handle sums the products of one output element (see csrc/sri_internal.h):
  * *ascending = 1: k = 0, 1, 2, ... as main.cpp:172 does (operators of more than 512 rows other than Dn_NN^-1);
  * *ascending = 0: inside every block of 8 consecutive k, the even ones before the odd ones.  Either way every

@@ -306,12 +306,18 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     import torch
 
     lib = sri.load_library()
-    for n, which, M, ld_extra, mark in [(256, 0, 40000, 0, "<256x128,dma>|<64x64,dma>"), (256, 1, 40000, 1, "<256x128,dma,lean>|<64x64,dma>"),
-                                        (256, 1, 49152, 0, "<256x128,dma,lean>|<128x128,dma>"), (256, 0, 16384, 3, "f64<128x128,dma>"),
-                                        (256, 1, 3000, 0, "f64<64x64,dma>"), (320, 0, 40000, 0, "<256x128,dma>+<64x256,dma>|<64x64,dma>"),
-                                        (300, 1, 36001, 2, "|<64x64,dma>"), (257, 0, 40000, 3, "<256+16x128,dma>,lean|<64x64,dma>"),
-                                        (512, 0, 40000, 0, "<256x128,dma>|<128x128,dma>"), (1024, 0, 4096, 0, "f64<128x128,dma>"),
-                                        (1023, 2, 1000, 1, "f64<128x128,dma"), (128, 0, 16384, 0, "f64<64x64,dma>"), (384, 0, 100000, 0, "<128x128,dma>|<64x64,dma>")]:
+    FLAT, MID = "f64<64x64,dma>", "f64<128x128,dma"
+    # (where 64 x 64 tiles for everything and "full rounds in the own geometry + the rest finer" are within a few per cent of each
+    # other in the model, either is accepted; the ascending-k operators have no 64 x 64 alternate: their plans are in two geometries)
+    cases = [(256, 0, 40000, 0, ("<256x128,dma>|<64x64,dma>", FLAT)), (256, 1, 40000, 1, ("<256x128,dma,lean>|<64x64,dma>", FLAT)),
+             (256, 1, 49152, 0, ("<256x128,dma,lean>|<128x128,dma>", FLAT)), (256, 0, 16384, 3, (MID,)), (256, 1, 3000, 0, (FLAT,)),
+             (320, 0, 40000, 0, ("<256x128,dma>+<64x256,dma>|<64x64,dma>", FLAT)), (300, 1, 36001, 2, ("|<64x64,dma>", FLAT)),
+             (257, 0, 40000, 3, ("<256+16x128,dma>,lean|<64x64,dma>", FLAT)), (512, 0, 40000, 0, ("<256x128,dma>|<128x128,dma>", FLAT)),
+             (1024, 0, 4096, 0, (MID,)), (1023, 2, 1000, 1, (MID,)), (128, 0, 16384, 0, (FLAT,)), (384, 0, 100000, 0, ("<128x128,dma>|<64x64,dma>", FLAT)),
+             (1024, 0, 20000, 0, ("<256x128,dma>|<128x128,dma>",)), (1024, 2, 20000, 1, ("<256x128,dma,lean>|<128x128,dma>",)),
+             (1050, 0, 20000, 0, ("dma",))]
+    mixed = 0
+    for n, which, M, ld_extra, marks in cases:
         op = sri.SpectralApply(n, which)
         rows = op.rows
         ld = rows + ld_extra
@@ -326,7 +332,8 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert mark in outs[1][2] and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
+        assert any(mark in outs[1][2] for mark in marks) and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
+        mixed += "|" in outs[1][2]
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which, M, outs[1][2])
         assert torch.equal(outs[1][1], outs[1][0][:, 0])
         if which == 1:
@@ -338,6 +345,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
                 ys.append(op.integrate(B, xb))
             assert torch.equal(ys[0], ys[1]), (n, M, "integrate", op.last_kernel)
         del Xd, outs
+    assert mixed >= 2, mixed
 
 
 @pytest.mark.parametrize("n", [16, 64, 256, 300, 321])
@@ -399,10 +407,9 @@ def test_apply_is_graph_capturable(sri):
     """sri_apply only enqueues a kernel (no allocation, attribute call or sync): capture it in a HIP graph."""
     import torch
 
-    n = 256
-    op = sri.SpectralApply(n, 0)
     # own geometry; the column plan's choice for a small panel (64 x 64 tiles); a planned launch in two geometries (two kernels)
-    for M, planned, mark in ((4096, False, "<256x128,dma>"), (4096, True, "<64x64,dma>"), (40000, True, "|")):
+    for n, M, planned, mark in ((256, 4096, False, "<256x128,dma>"), (256, 4096, True, "<64x64,dma>"), (1024, 20000, True, "|")):
+        op = sri.SpectralApply(n, 0)
         op.set_column_plan(planned)
         X = torch.rand((M, n), dtype=torch.float64, device="cuda") * 2 - 1
         Y = torch.zeros_like(X)

@@ -80,14 +80,17 @@ def test_quaternion_rhs_kernel(sri):
 
 @pytest.mark.parametrize("n,rods", [(16, 5), (17, 40), (10, 3), (33, 70), (64, 333), (65, 100), (129, 50), (200, 77),
                                     (256, 700), (257, 96), (513, 33), (300, 41), (385, 70), (641, 19)])
-def test_fused_quaternion_step(sri, oracle, n, rods):
+@pytest.mark.parametrize("planned", ["0", "1"])     # SRI_APPLY_COLUMN_PLAN: the operator's own tile geometry / a finer one for a small batch
+def test_fused_quaternion_step(sri, oracle, n, rods, planned, monkeypatch):
     """sri_rod_quaternion_step (the right-hand side formed in the apply's store stage) against
     (a) the unfused composition integrate -> strain -> rhs of the same library: bit-identical, same operation order;
     (b) numpy on the oracle's Dn_NN^-1 / Dn_IN: 1e-12 relative Frobenius.  Covers all three geometries, the
     register path (m < 16), tails (m % 16 != 0), whole multiples (m % 16 == 0), ragged last column tiles and the 128-row
-    geometry with several row blocks (299, 384, 640 rows: it replaces a half-empty 256-row block)."""
+    geometry with several row blocks (299, 384, 640 rows: it replaces a half-empty 256-row block) — and, planned, the same
+    batches in the finer geometry the column plan gives a fraction of a round of tiles (one geometry per fused launch)."""
     import torch
 
+    monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", planned)             # read when the handles are created
     m = n - 1
     rng = np.random.default_rng(n * 1000 + rods)
     qe = rng.uniform(-2, 2, size=(rods, 9))
@@ -109,6 +112,11 @@ def test_fused_quaternion_step(sri, oracle, n, rods):
     # the in-kernel convergence monitor: bits of max |tip - previous tip|, exactly
     assert update.view(torch.float64).item() == (tips - tips_prev).abs().max().item()
     assert torch.equal(rod.quaternion_step(dqe, dG, dq0), ref)                 # without tips / monitor
+    kernel = rod.last_apply_kernel
+    assert "quat" in kernel, kernel
+    if n >= 129:
+        own = "<128x128," if n in (129, 300, 385, 641) else "<256x128,"
+        assert (own in kernel) == (planned == "0"), (n, rods, planned, kernel)    # (planned: these batches are a fraction of a round)
     # (b) oracle matrices
     Dinv, Din = oracle.integration(n)
     w = Dinv @ Din
@@ -123,11 +131,12 @@ def test_fused_quaternion_step(sri, oracle, n, rods):
     assert rel <= 1e-12, rel
 
 
-def test_fused_step_lean_and_edge_safe_kernels_agree(sri):
+def test_fused_step_lean_and_edge_safe_kernels_agree(sri, monkeypatch):
     """The fused step of an N = 2^p grid (255, 127, 1023 rows) has the same two variants as the plain odd-row-count apply
     (tests/test_apply_gpu.py::test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides): same bits."""
     import torch
 
+    monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", "0")                 # (these batches would go to 64 x 64 tiles, which have no lean twin)
     for n, rods in [(256, 1500), (128, 900), (512, 300)]:
         m = n - 1
         g = torch.Generator(device="cuda").manual_seed(n)
