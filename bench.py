@@ -123,8 +123,23 @@ def launch_ranks(n_gpus: int, argv, script: str = None) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
     out, _ = proc.communicate()
-    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
-    rest = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip() and not ln.strip().startswith("{")]
+    # rank 0's result line: the last line that holds a JSON object (two ranks share this pipe: should another rank's chatter
+    # ever land on the same line, the object is still taken from its opening brace)
+    lines, rest = [], []
+    for ln in out.decode(errors="replace").splitlines():
+        at = ln.find('{"')
+        obj = None
+        if at >= 0:
+            try:
+                obj, _ = json.JSONDecoder().raw_decode(ln[at:])
+            except ValueError:
+                obj = None
+        if isinstance(obj, dict):
+            lines.append(json.dumps(obj))
+            if ln[:at].strip():
+                rest.append(ln[:at])
+        elif ln.strip():
+            rest.append(ln)
     for ln in rest:                                        # launcher chatter is not part of the contract
         print(ln, file=sys.stderr)
     if lines:
