@@ -70,16 +70,25 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
     // take 101 us where 3 rounds of 5 per CU would take 130)
     t = std::ceil(tiles / cus) * g.stream_us;
     per_tile = std::ceil(tiles / cus) * g.tile_us;
+    // ... and every row block re-reads the panel: 64 columns x K x 8 bytes in and 64 x 64 x 8 out per tile, at what the memory
+    // system gives a launch whose panel no longer fits the 256 MB Infinity Cache (measured: N = 320, 209 664 columns in 64 x 64
+    // tiles alone move 3.2 GB in 756 us) — above four row blocks this, not the MFMA pipe, is what bounds the small tiles
+    const double k_bytes = 16.0 * nk * 8.0;
+    const double bytes = tiles * (g.bn * k_bytes + g.bn * 64.0 * 8.0);
+    const double panel = static_cast<double>(cols) * k_bytes;
+    const double bytes_per_us = panel <= 128e6 ? 5.2e6 : 4.3e6;
+    if (bytes / bytes_per_us > t * nk + per_tile) return bytes / bytes_per_us + kLaunchOverheadUs;
   } else {
-    // whole rounds; the tiles behind the last full round go to the FIRST workgroups of a grid that sits per_cu to a CU
-    // (measured: 768 tiles of 128 x 128 take 125 us, nearly two full rounds)
+    // whole rounds; the tiles behind the last full round go to the FIRST workgroups of a grid that sits per_cu to a CU: up to one
+    // per CU they may or may not share (measured: 768 tiles of 128 x 128 take 125 us where two full rounds take 134 and
+    // "one round + one tile alone" 101; 768 tiles of 64 x 256 behave like the latter) — the mean of both
     const double full = std::floor(tiles / slots);
     const double rem = tiles - full * slots;
     t = full * g.us[g.per_cu - 1];
     if (rem > 0.0) {
-      int share = static_cast<int>(std::ceil(rem * g.per_cu / cus));
-      if (share > g.per_cu) share = g.per_cu;
-      t += g.us[share - 1];
+      if (g.per_cu == 2 && rem <= cus / 2) t += g.us[0];                               // (a few tiles: each on a CU of its own)
+      else if (g.per_cu == 2 && rem <= cus) t += 0.5 * (g.us[0] + g.us[1]);
+      else t += g.us[g.per_cu - 1];
     }
   }
   return t * nk + per_tile + kLaunchOverheadUs;
@@ -124,7 +133,9 @@ inline Choice choose(const Launch* primary, int num_primary, const Launch* alter
       }
     }
   }
-  if (cand.alt >= 0 && cand.model_us <= 0.95 * best.model_us && cand.model_us + 3.0 <= best.model_us) return cand;
+  // (short k: the tile ends, which the table folds into its per-chunk figures at K = 256, weigh more — ask for more)
+  const double needed = nk >= 16 ? 0.95 : 0.90;
+  if (cand.alt >= 0 && cand.model_us <= needed * best.model_us && cand.model_us + 3.0 <= best.model_us) return cand;
   return best;
 }
 

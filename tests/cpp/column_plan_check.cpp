@@ -78,7 +78,7 @@ int main() {
     CHECK(c.alt < num_alt, "alt %d of %d", c.alt, num_alt);
     CHECK(c.primary_cols == M || c.primary_cols % 256 == 0, "kept %zu: whole tiles of every primary geometry", c.primary_cols);
     CHECK(c.model_us <= c.primary_only_us, "model %.2f > primary only %.2f", c.model_us, c.primary_only_us);
-    if (c.alt >= 0) CHECK(c.model_us <= 0.95 * c.primary_only_us, "deviates for %.2f against %.2f", c.model_us, c.primary_only_us);
+    if (c.alt >= 0) CHECK(c.model_us <= (nk >= 16 ? 0.95 : 0.90) * c.primary_only_us, "deviates for %.2f against %.2f", c.model_us, c.primary_only_us);
     const Choice none = choose(own, num_own, alt, 0, M, nk, cus);
     CHECK(none.alt < 0 && none.primary_cols == M, "no alternates: nothing to choose");
   }
