@@ -316,7 +316,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
              (1024, 0, 4096, 0, (MID,)), (1023, 2, 1000, 1, (MID,)), (128, 0, 16384, 0, (FLAT,)), (384, 0, 100000, 0, ("<128x128,dma>|<64x64,dma>", FLAT)),
              (1024, 0, 20000, 0, ("<256x128,dma>|<128x128,dma>",)), (1024, 2, 20000, 1, ("<256x128,dma,lean>|<128x128,dma>",)),
              (1050, 0, 20000, 0, ("dma",))]
-    mixed = 0
+    mixed = finer = 0
     for n, which, M, ld_extra, marks in cases:
         op = sri.SpectralApply(n, which)
         rows = op.rows
@@ -332,8 +332,10 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert any(mark in outs[1][2] for mark in marks) and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
+        # (the expected kernels are what the cost model picks today; where its candidates are close the own geometry may stay)
+        assert (any(mark in outs[1][2] for mark in marks) or outs[1][2] == outs[0][2]) and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
         mixed += "|" in outs[1][2]
+        finer += outs[1][2] != outs[0][2]
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which, M, outs[1][2])
         assert torch.equal(outs[1][1], outs[1][0][:, 0])
         if which == 1:
@@ -345,7 +347,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
                 ys.append(op.integrate(B, xb))
             assert torch.equal(ys[0], ys[1]), (n, M, "integrate", op.last_kernel)
         del Xd, outs
-    assert mixed >= 2, mixed
+    assert mixed >= 2 and finer >= 10, (mixed, finer)
 
 
 @pytest.mark.parametrize("n", [16, 64, 256, 300, 321])
