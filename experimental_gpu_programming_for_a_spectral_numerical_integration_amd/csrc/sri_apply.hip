@@ -96,6 +96,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->geo = rows_out <= 64 ? GEO_FLAT : ((rows_out <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
   // (tiles of one or two k chunks: the fused step needs four side buffers, which the 256-row geometry's ring leaves no room for)
   if (!square && h->geo == GEO_TALL && (rows + BK - 1) / BK < 3) h->geo = GEO_MID;
+  // SRI_APPLY_FORCE_GEO=m / f (diagnostics, A/B timing: profiles/r04_geometry_by_columns.log): the 128 x 128 / 64 x 64 geometry
+  // as the operator's own, whatever its rows
   if (const char* v = std::getenv("SRI_APPLY_FORCE_GEO")) { if (v[0] == 'm') h->geo = GEO_MID; else if (v[0] == 'f') h->geo = GEO_FLAT; }
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
