@@ -65,10 +65,13 @@ def main():
             op = sri.SpectralApply(rows + 1, sri.OP_DN, matrix=A)
             which = -1
         rows = op.rows
+        op.set_column_plan(case % 2 == 1)                        # odd cases: whatever the column plan picks for M columns
         big = rows > 300
         M = int(rng.integers(1, 600 if big else 6000))
         if rng.random() < 0.15:
             M = int(rng.choice([1, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257]))
+        if case % 2 == 1 and 129 <= rows <= 300 and rng.random() < 0.08:
+            M = int(rng.integers(33000, 60000))                  # more than a round of 256 x 128 tiles: plans in two geometries
         ldx = rows + int(rng.choice([0, 0, 1, 2, 3, 7, 16]))
         ldy = rows + int(rng.choice([0, 0, 1, 2, 5, 8]))
         offx, offy = int(rng.integers(0, 5)), int(rng.integers(0, 5))
