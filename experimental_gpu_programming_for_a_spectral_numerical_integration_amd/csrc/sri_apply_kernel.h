@@ -155,6 +155,16 @@ struct Geo {
   static constexpr int XB_WAVE_BYTES = 8 * X_DMA_PER_WAVE * 8 > 256 ? 8 * X_DMA_PER_WAVE * 8 : 256;
   static constexpr int XB_BYTES = 2 * NW * XB_WAVE_BYTES;
   static_assert(8 * X_DMA_PER_WAVE * 8 <= XB_WAVE_BYTES, "one 8-byte entry per column of the wave's X pieces");
+  // The rank-1 term as an EPILOGUE on the LDS-DMA path (sri_integrate of an operator with a whole number of k chunks: every
+  // integration operator of an N = 16 q + 1 grid): x_base of the tile's BN columns and the factors w of its A_ROWS rows travel
+  // with the tile's first stage into a side buffer behind the ring, two tiles in flight — where that does not cost a resident
+  // workgroup (not the 64 x 256 geometry: two workgroups per CU at 80 KiB each leave no room).
+  static constexpr int R1_XB_BYTES = BN * 8;
+  static constexpr int R1_W_BYTES = A_ROWS * 8;
+  static constexpr int R1_SIDE_BYTES = R1_XB_BYTES + R1_W_BYTES;
+  static constexpr int R1_BYTES = 2 * R1_SIDE_BYTES;
+  static constexpr bool R1X_OK = (160 * 1024) / (LDS_BYTES + R1_BYTES) == (160 * 1024) / LDS_BYTES && R1_XB_BYTES % 256 == 0 &&
+                                 R1_W_BYTES % 16 == 0 && (R1_W_BYTES + 1023) / 1024 <= NW;
   // the fused quaternion epilogue's side buffers: only geometries that satisfy this may be instantiated with EPI_QUAT
   static constexpr bool QUAT_OK = STRIP == 0 && LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
                                   (P1_BYTES + 1023) / 1024 + 1 <= NW;   // P1 slab and previous tips: at most one 1-KiB DMA piece per wave
@@ -411,6 +421,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool FOLD = RANK1 && (TAIL || !DMA);
   constexpr bool RANK1_EPI = RANK1 && !FOLD;
   constexpr bool XBUF = FOLD && DMA;                  // x_base rides through the LDS side buffer (Geo::XB_BYTES)
+  // the epilogue form with its operands staged in LDS (Geo::R1_BYTES) and the plain epilogue's stores: tiles of >= 3 k chunks
+  constexpr bool R1X = RANK1_EPI && DMA && EPI == EPI_NONE && G::R1X_OK && SRI_STORE_SADDR != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NW = G::NW, NSTAGE = G::NSTAGE, AHEAD = G::AHEAD;
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0;
@@ -625,10 +637,41 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       }
     }
   };
+  // R1X, first stage of a tile: x_base of the tile's BN columns (4-byte granules, so that the caller's array can be clamped at
+  // its end) and w of its A_ROWS rows (the handle's own, padded array) into side buffer (tile sequence parity).  In front of the
+  // stage's own pieces, like the coefficient pieces of EPI_QUAT: every wave passes the wait and the barrier of stage (tile, 0)
+  // before the tile's epilogue, which therefore reads landed data; two buffers suffice for tiles of >= 3 k chunks (issue_qe).
+  char* const r1_side = smem + G::LDS_BYTES;
+  auto issue_r1 = [&]() __attribute__((always_inline)) {
+    if constexpr (R1X) {
+      if (kc_i == 0 && p.nk >= 3) {
+        const ApplyArgs q = SRI_ARGS_HERE;
+        char* buf = r1_side + (tseq_i & 1u) * G::R1_SIDE_BYTES;
+        const size_t total = q.m * 8;
+#pragma unroll
+        for (int i = 0; i < (G::R1_XB_BYTES / 256 + NW - 1) / NW; ++i) {
+          const int chunk = wid + i * NW;                              // wave-uniform
+          if (chunk * 256 < G::R1_XB_BYTES) {
+            size_t src = col0_i * 8 + chunk * 256 + lane * 4;
+            src = src + 4 <= total ? src : total - 4;                  // ragged last tile: re-read valid bytes (never used)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(q.xb) + src),
+                                             (__attribute__((address_space(3))) void*)(buf + chunk * 256), 4, 0, 0);
+          }
+        }
+        const int pw = NW - 1 - wid;                                   // wave-uniform: the last waves take the row factors
+        if (pw * 1024 < G::R1_W_BYTES && pw * 1024 + lane * 16 < G::R1_W_BYTES) {
+          const uint32_t rb = tile_i / q.col_tiles;
+          lds_dma16(reinterpret_cast<const char*>(q.w + static_cast<size_t>(rb) * G::BM) + pw * 1024 + lane * 16,
+                    buf + G::R1_XB_BYTES + pw * 1024);
+        }
+      }
+    }
+  };
   // Fetch the stage under the cursor into ring slot slot_i; advance the cursor.
   auto stage_issue = [&]() __attribute__((always_inline)) {
     issue_qe();
     issue_xb();
+    issue_r1();
     char* sA = smem + slot_i * G::STAGE_BYTES;
     const char* gA = abase + static_cast<size_t>(kc_i) * G::A_BYTES;
     if (!(ABL & 1) || abl_first) {
@@ -670,7 +713,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // the operator slab, the rest the X panel.  Lets the main loop drop the pieces between MFMA groups.
   auto issue_piece = [&](int idx) __attribute__((always_inline)) {
     char* sA = smem + slot_i * G::STAGE_BYTES;
-    if (idx == 0) { issue_qe(); issue_xb(); }
+    if (idx == 0) { issue_qe(); issue_xb(); issue_r1(); }
     if (idx < G::A_DMA_PER_WAVE) {
       if (!(ABL & 1) || abl_first) {
         int i = wid + idx * NW;
@@ -861,7 +904,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // lane (j = lane & 15, g = lane >> 4): acc[tm][tn][r] = Y[row_base + 32*(tm>>1) + (tm&1)][col_base + 16*tn + 4*r]
   // Optional by-product: the tip-node value of every column (row 0 of the first row block), the "final
   // integrated state" a multi-GPU run reassembles.  Row 0 sits in acc[0][tn][r] of the lanes with c == 0.
-  auto emit_tips = [&](const ApplyArgs& q, uint32_t rb, size_t col_base) __attribute__((always_inline)) {
+  // `folded_in`: the accumulators already carry the rank-1 term (the R1X epilogue applies it in place)
+  auto emit_tips = [&](const ApplyArgs& q, uint32_t rb, size_t col_base, bool folded_in = false) __attribute__((always_inline)) {
     if (q.tips == nullptr || rb != 0 || wm != 0) return;      // wave-uniform
     if (c != 0) return;
 #pragma unroll
@@ -871,7 +915,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         const size_t col = col_base + tn * 16 + r * 4;
         if (col < q.m) {
           double v = acc[0][tn][r];
-          if constexpr (RANK1_EPI) v -= q.w[0] * q.xb[col];
+          if constexpr (RANK1_EPI) { if (!folded_in) v = __builtin_fma(-q.w[0], q.xb[col], v); }
           q.tips[col] = v;
         }
       }
@@ -941,7 +985,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
               double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
               if constexpr (RANK1_EPI) {
                 const double wv = q.w[row + e];
-                qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
+                qw = __builtin_fma(-wv, xb[0], qw); qx = __builtin_fma(-wv, xb[1], qx); qy = __builtin_fma(-wv, xb[2], qy); qz = __builtin_fma(-wv, xb[3], qz);
               }
               if (tip_lane && t == 0 && e == 0) {
                 q.tips[col + 0] = qw; q.tips[col + 1] = qx; q.tips[col + 2] = qy; q.tips[col + 3] = qz;
@@ -1014,7 +1058,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           double qw = acc[2 * t + e][tn][0], qx = acc[2 * t + e][tn][1], qy = acc[2 * t + e][tn][2], qz = acc[2 * t + e][tn][3];
           if constexpr (RANK1_EPI) {
             const double wv = q.w[row + e];
-            qw -= wv * xb[0]; qx -= wv * xb[1]; qy -= wv * xb[2]; qz -= wv * xb[3];
+            qw = __builtin_fma(-wv, xb[0], qw); qx = __builtin_fma(-wv, xb[1], qx); qy = __builtin_fma(-wv, xb[2], qy); qz = __builtin_fma(-wv, xb[3], qz);
           }
           if (tip_lane && t == 0 && e == 0) {
             q.tips[col + 0] = qw; q.tips[col + 1] = qx; q.tips[col + 2] = qy; q.tips[col + 3] = qz;
@@ -1056,7 +1100,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // column tile wm — four 8-byte stores, 128 contiguous bytes per column.  `counted`: every column exists and the wave is on
   // the counted-store path: exactly four store INSTRUCTIONS must be issued whatever the number of valid rows (the stage waits
   // count them), so the rows that do not exist are masked out through exec, not branched around.
-  auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted) __attribute__((always_inline)) {
+  // `staged` (R1X epilogue): the rank-1 operands of this tile are in LDS (r1_side, buffer of the finished tile's parity)
+  auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted, const char* staged = nullptr) __attribute__((always_inline)) {
     if constexpr (G::STRIP != 0) {
       const uint32_t row = rb_c * G::BM + G::BM + c;
       const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + g;
@@ -1065,7 +1110,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int r = 0; r < 4; ++r) {
         v[r] = sacc[r];
         if constexpr (RANK1_EPI) {
-          if (row < q.rows_out && col_s + 4 * r < q.m) v[r] -= q.w[row] * q.xb[col_s + 4 * r];
+          if (staged != nullptr) {                                   // (full tile: every column exists; w is zero beyond the last row)
+            const double ws = *reinterpret_cast<const double*>(staged + G::R1_XB_BYTES + (G::BM + c) * 8);
+            const double xs = *reinterpret_cast<const double*>(staged + (wn * (TN * 16) + wm * 16 + g + 4 * r) * 8);
+            v[r] = __builtin_fma(-ws, xs, v[r]);
+          } else if (row < q.rows_out && col_s + 4 * r < q.m) {
+            v[r] = __builtin_fma(-q.w[row], q.xb[col_s + 4 * r], v[r]);
+          }
         }
       }
       if (counted) {
@@ -1094,7 +1145,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       }
     }
   };
-  constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && !RANK1_EPI && (ABL & 128) == 0 && EPI == EPI_NONE;
+  constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && (!RANK1_EPI || R1X) && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
     const ApplyArgs q = SRI_ARGS_HERE;
@@ -1121,10 +1172,25 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) keep_live(acc[tm][tn]);
       return false;
-    } else if (SADDR_STORES && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + (TM / 2 >= 2 ? 1 : 0))) {
+    } else if (SADDR_STORES && (!R1X || q.nk >= 3) && (col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + ((TM / 2 >= 2 && !R1X) ? 1 : 0))) {
       // Every column of the tile exists and this WAVE's 64 rows do too, except possibly the very last one (255, 1023, ...
       // rows): NSTORE 16-byte stores, straight-line, no vector-ALU address arithmetic (store16_sv).  Decided per wave —
       // the counted waits are per wave as well.
+      // R1X: the rank-1 term, one fused multiply-add per accumulator element AS IT IS PACKED for its store (updating the
+      // accumulator tuples in place costs 150 spilled registers: every element write copies a tuple): the chain position of one
+      // more k behind the last chunk — what the folded form (rows % 16 != 0) computes inside the product, hence the same bits as a
+      // product over the operands extended by (-w | x_base).  Operands from the tile's side buffer: this lane's TM rows' factors
+      // (two 16-byte reads) and its 4 TN columns' x_base (8-byte reads at constant offsets from one lane address).
+      [[maybe_unused]] const char* staged = nullptr;
+      [[maybe_unused]] const char* xcol = nullptr;
+      [[maybe_unused]] d2 wv2[TM / 2];
+      if constexpr (R1X) {
+        staged = r1_side + (tseq_c & 1u) * G::R1_SIDE_BYTES;
+        const char* wrow = staged + G::R1_XB_BYTES + (wm * (TM * 16) + 2 * c) * 8;
+        xcol = staged + (wn * (TN * 16) + g) * 8;
+#pragma unroll
+        for (int t = 0; t < TM / 2; ++t) wv2[t] = *reinterpret_cast<const d2*>(wrow + 256 * t);
+      }
       const bool odd = (SRI_TAIL_ABL & 4) == 0 && rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1;   // wave-uniform: the last row pair is half empty
       const size_t ldy8 = q.ldy * sizeof(double);
       char* const ybase = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16)) * ldy8 +
@@ -1140,9 +1206,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
               cb += 4 * ldy8;                                                       // columns g + 4 (tn * 4 + r)
               asm volatile("" : "+s"(cb));                                          // one running base, not 16 hoisted (and spilled) ones
             }
+            [[maybe_unused]] double xs = 0.0;
+            if constexpr (R1X) xs = *reinterpret_cast<const double*>(xcol + (tn * 16 + 4 * r) * 8);
             static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
               constexpr int t = decltype(tc)::value;
-              if constexpr (ODD && t == TM / 2 - 1) {
+              if constexpr (R1X) {
+                store16_sv<NT, 256 * t>(cb, ylane, pack2(__builtin_fma(-wv2[t][0], xs, acc[2 * t][tn][r]), __builtin_fma(-wv2[t][1], xs, acc[2 * t + 1][tn][r])));
+              } else if constexpr (ODD && t == TM / 2 - 1) {
                 // The wave's last row pair is half empty (lane 15 holds row rows - 1 and a row that does not exist).  Every
                 // lane stores its pair shifted UP by one row instead: {row 2c - 1 (from the lane above; lane 0: the last row
                 // of the previous pair), row 2c} at its usual address - 8.  Still one 16-byte store per lane, all 64 lanes, 256
@@ -1160,10 +1230,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       };
       if (q.nt_stores != 0) { if (odd) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{}); }
       else { if (odd) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{}); }
-      store_strip(q, rb_c, col0_c, ypanel, true);
+      store_strip(q, rb_c, col0_c, ypanel, true, staged);
       emit_tips(q, rb_c, col_base);
       return true;
-    } else if (!SADDR_STORES && full) {                     // (with SADDR_STORES every tile that is `full` took the branch above)
+    } else if ((!SADDR_STORES || R1X) && full) {                     // (with SADDR_STORES every tile that is `full` took the branch above)
       // rank-1 term: this lane's TM row factors once per tile, one x_base value per column (not per store)
       double wv[TM / 2][2];
       if constexpr (RANK1_EPI) {
@@ -1188,8 +1258,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
               double* yp = ypanel + col * q.ldy + row;
               double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
               if constexpr (RANK1_EPI) {
-                v0 -= wv[t][0] * xbv;
-                v1 -= wv[t][1] * xbv;
+                v0 = __builtin_fma(-wv[t][0], xbv, v0);
+                v1 = __builtin_fma(-wv[t][1], xbv, v1);
               }
               if (all_rows || row + 1 < q.rows_out) store_y<NT>(reinterpret_cast<d2*>(yp), pack2(v0, v1));   // 16 B, 8-byte aligned is fine
               else *yp = v0;                                                                 // the lane holding the last row
@@ -1215,8 +1285,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
             const uint32_t row = row_base + 32 * t;
             double v0 = acc[2 * t][tn][r], v1 = acc[2 * t + 1][tn][r];
             if constexpr (RANK1_EPI) {
-              if (row < q.rows_out) v0 -= q.w[row] * xbv;
-              if (row + 1 < q.rows_out) v1 -= q.w[row + 1] * xbv;
+              if (row < q.rows_out) v0 = __builtin_fma(-q.w[row], xbv, v0);
+              if (row + 1 < q.rows_out) v1 = __builtin_fma(-q.w[row + 1], xbv, v1);
             }
             if (DMA && row + 1 < q.rows_out) {
               *reinterpret_cast<d2*>(ycol + row) = d2{v0, v1};
@@ -1708,7 +1778,8 @@ static int prepare(int dev) {
   std::lock_guard<std::mutex> lock(prepare_mutex());
   if (residency<G, DMA, RANK1, TAIL, EPI, BUFS, ASC, LEAN>(dev).load(std::memory_order_relaxed) != 0) return SRI_OK;
   const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>;
-  constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : 0;        // FOLD on the LDS-DMA path: x_base side buffer at the end
+  // FOLD on the LDS-DMA path: x_base side buffer at the end; the epilogue form (whole k chunks): x_base and w side buffers
+  constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : ((DMA && RANK1 && !TAIL && EPI == EPI_NONE && G::R1X_OK && SRI_STORE_SADDR != 0) ? G::R1_BYTES : 0);
   constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
   // the attribute is the most any launch of this kernel may ask for
@@ -1743,7 +1814,8 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;
   }
-  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + ((DMA && RANK1 && TAIL) ? G::XB_BYTES : 0);
+  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) +
+                      ((DMA && RANK1 && TAIL) ? G::XB_BYTES : ((DMA && RANK1 && !TAIL && EPI == EPI_NONE && G::R1X_OK && SRI_STORE_SADDR != 0) ? G::R1_BYTES : 0));
   SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>), dim3(grid), dim3(G::THREADS), lds, stream, args));
   return SRI_OK;
 }

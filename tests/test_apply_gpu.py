@@ -350,9 +350,14 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     assert mixed >= 2 and finer >= 10, (mixed, finer)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 300, 321])
-def test_integrate_matches_oracle(sri, oracle, n):
-    """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T)."""
+@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 129, 257, 273, 289, 513])
+@pytest.mark.parametrize("planned", [False, True])
+def test_integrate_matches_oracle(sri, oracle, n, planned):
+    """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T).  Both forms of the initial-value term: folded into
+    the product where the last k chunk has a free slot (n - 1 not a multiple of 16), and as the store stage's one fused
+    multiply-add per element where it has not (every N = 16 q + 1 grid: operands staged in LDS with the tile's first stage;
+    273 / 289 / 321: the strip and the 32- and 64-row last parts) — the same bits by construction, in the operator's own
+    geometry and in whatever the column plan picks for 515 columns."""
     import torch
 
     M = 515
@@ -360,8 +365,16 @@ def test_integrate_matches_oracle(sri, oracle, n):
     B = uniform_panel(n - 1, M, seed=11)
     xb = np.random.default_rng(5).uniform(-1, 1, size=M)
     op = sri.SpectralApply(n, sri.OP_DNN_INV)
-    Y = op.integrate(_torch_panel(B), torch.from_numpy(xb).cuda())
+    op.set_column_plan(planned)
+    tips = torch.full((M,), 7.0, dtype=torch.float64, device="cuda")
+    Yd = torch.empty((M, n - 1), dtype=torch.float64, device="cuda")
+    Bd, xbd = _torch_panel(B), torch.from_numpy(xb).cuda()
+    assert sri.load_library().sri_integrate_tips(op._h, Bd.data_ptr(), n - 1, xbd.data_ptr(), Yd.data_ptr(), n - 1, M, tips.data_ptr(), None) == 0
     torch.cuda.synchronize()
+    assert torch.equal(tips, Yd[:, 0].contiguous())            # the tip row carries the term as well
+    Y = op.integrate(Bd, xbd)
+    torch.cuda.synchronize()
+    assert torch.equal(Y, Yd)
     Y = np.asfortranarray(Y.cpu().numpy().T)
     Yref = oracle.integrate(Dinv, Din, B, xb)
     rhs = B - np.outer(Din, xb)
@@ -377,11 +390,11 @@ def test_integrate_matches_oracle(sri, oracle, n):
     lib = oracle.lib()
     Ym = np.zeros((n - 1, M), order="F")
     assert not op.ascending_k                        # the integration operator keeps the paired order at every size
-    if (n - 1) % 16 != 0:                            # (with a whole number of k chunks the term is an epilogue: product, then one subtraction)
-        assert lib.sri_model_apply(oracle.MODEL_KERNEL, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
-                                   Xext.ctypes.data_as(oracle._dp), n, Ym.ctypes.data_as(oracle._dp), n - 1, M) == 0
-        assert np.array_equal(Y, Ym)
-    # backward error is measured against |Dinv| (|B| + |Din||xb|): the epilogue form reassociates the rank-1 term
+    # (with a whole number of k chunks the term is the store stage's fused multiply-add — the chain position of one more k)
+    assert lib.sri_model_apply(oracle.MODEL_KERNEL, n - 1, n, Aext.ctypes.data_as(oracle._dp), n - 1,
+                               Xext.ctypes.data_as(oracle._dp), n, Ym.ctypes.data_as(oracle._dp), n - 1, M) == 0
+    assert np.array_equal(Y, Ym), (n, planned, op.last_kernel)
+    # backward error is measured against |Dinv| (|B| + |Din||xb|)
     scale = np.abs(Dinv) @ (np.abs(B) + np.outer(np.abs(Din), np.abs(xb)))
     assert np.max(np.abs(Y - Yref) / scale) <= backward_tol(n)
 

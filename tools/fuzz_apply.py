@@ -119,7 +119,7 @@ def main():
         if which == sri.OP_DNN_INV and rng.random() < 0.7:
             # sri_integrate: Y = Dinv B - w x_base^T with w = Dinv Din.  When the last k chunk has a free slot (rows % 16 != 0)
             # the term rides in the product: the FMA chain over [Dinv | -w] and [B; x_base].  Otherwise it is the kernel's
-            # epilogue: the chain over Dinv and B, then one product and one subtraction (two roundings).
+            # epilogue: the chain over Dinv and B, then ONE fused multiply-add — the same chain, one link longer.
             xb = rng.uniform(-1, 1, M)
             dxb = to_dev(xb)
             ybuf.fill_(-7.25)
@@ -130,12 +130,10 @@ def main():
             w = np.zeros(rows)
             for k in range(rows):
                 w = w + Dinv[:, k] * Din[k]
-            if rows % 16 != 0:
-                Aext = np.asfortranarray(np.concatenate([Dinv, -w[:, None]], axis=1))
-                Xext = np.asfortranarray(np.concatenate([Xc, xb[None, :]], axis=0))
-                want_i = oracle.model_apply(Aext, Xext, model)
-            else:
-                want_i = want - np.outer(w, xb)
+            # (either form — folded into the product, or the store stage's fused multiply-add — is the chain over the extended operands)
+            Aext = np.asfortranarray(np.concatenate([Dinv, -w[:, None]], axis=1))
+            Xext = np.asfortranarray(np.concatenate([Xc, xb[None, :]], axis=0))
+            want_i = oracle.model_apply(Aext, Xext, model)
             integ_ok = rc == 0 and np.array_equal(np.asfortranarray(Yi[:, :rows].T), want_i) and bool(np.all(Yi[:, rows:] == -7.25))
         if not (ok and pad_ok and tip_ok and host_ok and integ_ok):
             bad += 1
