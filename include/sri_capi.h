@@ -144,8 +144,9 @@ int sri_apply_tips(sri_apply_t *h, const double *dX, size_t ldx, double *dY, siz
 /* Position/quaternion integration in one call, main.cpp:172 batched:
  *   Y = Dnn_inv * (B - Din * x_base^T)
  * for a handle created with SRI_OP_DNN_INV.  dB: (n-1) x M, d_x_base: M doubles (the base-node
- * value of every column), all device pointers.  The rank-1 initial-value term is applied as
- * Y -= (Dnn_inv*Din) * x_base^T in the kernel epilogue. */
+ * value of every column), all device pointers.  The rank-1 initial-value term -(Dnn_inv*Din) * x_base^T is one more
+ * link (k = n - 1) of every output element's chain of fused multiply-adds: inside the product where the last k chunk has
+ * a free slot ((n - 1) % 16 != 0), in the kernel's store stage otherwise — the same bits either way. */
 int sri_integrate(sri_apply_t *h, const double *dB, size_t ldb, const double *d_x_base,
                   double *dY, size_t ldy, size_t M, void *hip_stream);
 
