@@ -77,7 +77,7 @@ def test_host_panel_in_place(sri):
     assert np.array_equal(buf, want)
 
 
-@pytest.mark.parametrize("n,M", [(256, 12_000), (64, 45_000), (17, 300)])
+@pytest.mark.parametrize("n,M", [(256, 12_000), (64, 45_000), (17, 300), (257, 40_000), (129, 70_001)])   # (257, 129: the term as the store stage's fused multiply-add, operands staged from the device slot)
 def test_integrate_host_equals_device(sri, n, M):
     op = sri.SpectralApply(n, sri.OP_DNN_INV)
     B = uniform_panel(n - 1, M, 11)
