@@ -92,8 +92,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   // (0.77 of the MFMA peak at K = 128, 0.86 from K = 384 on: tile ends amortise over K) is the better choice whenever it
   // saves a half-empty 256-row block, i.e. when the last 256-row block would hold at most 128 rows — measured N = 320:
   // 0.54 -> 0.71, N = 384: 0.66 -> 0.86 of the peak (profiles/r03_sweep_n.jsonl).
-  const bool half_empty_last_block = rows_out > 256 && (rows_out - 1) % 256 < 128;
-  h->geo = rows_out <= 64 ? GEO_FLAT : ((rows_out <= 128 || half_empty_last_block) ? GEO_MID : GEO_TALL);
+  h->geo = plan::own_geometry(rows_out);                          // (sri_column_plan.h)
   // (tiles of one or two k chunks: the fused step needs four side buffers, which the 256-row geometry's ring leaves no room for)
   if (!square && h->geo == GEO_TALL && (rows + BK - 1) / BK < 3) h->geo = GEO_MID;
   // SRI_APPLY_FORCE_GEO=m / f (diagnostics, A/B timing: profiles/r04_geometry_by_columns.log): the 128 x 128 / 64 x 64 geometry
@@ -160,25 +159,17 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   // (from the Infinity Cache as far as it reaches), which is why thinner last parts do not pay (DESIGN.md §4 "Other grid sizes").
   // SRI_APPLY_NO_PARTS=1 keeps every operator whole (A/B, tests).
   {
-    const uint32_t units = (rows + 63) / 64;
     const char* no_parts = std::getenv("SRI_APPLY_NO_PARTS");
     const char* no_strip = std::getenv("SRI_APPLY_NO_STRIP");       // A/B: thin last rows as a part of their own instead of a strip
     int np = 0;
     if (square && !(no_parts && no_parts[0] == '1')) {
-      if (units >= 5 && units % 4 == 1) {
-        const uint32_t full = 256 * (units / 4), rest = rows - full;
-        if (rest <= 16 && !(no_strip && no_strip[0] == '1')) {
-          // 256 a + r rows, r <= 16: the first a - 1 row blocks as they are, the last one with the r rows as its strip
-          if (full > 256) { h->parts[np].geo = GEO_TALL; h->parts[np].row0 = 0; h->parts[np].rows = full - 256; h->parts[np].row_blocks = full / 256 - 1; ++np; }
-          h->parts[np].geo = GEO_TALL_STRIP; h->parts[np].row0 = full - 256; h->parts[np].rows = 256 + rest; h->parts[np].row_blocks = 1; ++np;
-        } else {
-          h->parts[np].geo = GEO_TALL; h->parts[np].row0 = 0; h->parts[np].rows = full; h->parts[np].row_blocks = full / 256; ++np;
-          h->parts[np].geo = rest <= GeoWide32::BM ? GEO_WIDE32 : GEO_WIDE; h->parts[np].row0 = full; h->parts[np].rows = rest; h->parts[np].row_blocks = 1; ++np;
-        }
-      } else if (units == 3) {
-        const uint32_t rest = rows - 128;
-        h->parts[np].geo = GEO_MID; h->parts[np].row0 = 0; h->parts[np].rows = 128; h->parts[np].row_blocks = 1; ++np;
-        h->parts[np].geo = rest <= GeoWide32::BM ? GEO_WIDE32 : GEO_WIDE; h->parts[np].row0 = 128; h->parts[np].rows = rest; h->parts[np].row_blocks = 1; ++np;
+      plan::RowPart rp[2];
+      np = plan::row_parts(rows, !(no_strip && no_strip[0] == '1'), rp);   // (sri_column_plan.h; tests/cpp/column_plan_check.cpp)
+      for (int i = 0; i < np; ++i) {
+        h->parts[i].geo = rp[i].geo;
+        h->parts[i].row0 = rp[i].row0;
+        h->parts[i].rows = rp[i].rows;
+        h->parts[i].row_blocks = rp[i].row_blocks;
       }
     }
     if (np != 0) {

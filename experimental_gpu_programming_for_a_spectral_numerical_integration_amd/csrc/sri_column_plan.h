@@ -28,6 +28,49 @@ namespace plan {
 // ids as sri::GeoId (sri_apply_kernel.h)
 enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, GEO_COUNT = 6 };
 
+// ---- rows: the operator's own geometry, and the parts it is cut into (sri_apply.hip's create_from_matrix) ----------------------
+// Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry is
+// the better choice whenever it saves a half-empty 256-row block (round 3).
+inline int own_geometry(uint32_t rows_out) {
+  const bool half_empty_last_block = rows_out > 256 && (rows_out - 1) % 256 < 128;
+  return rows_out <= 64 ? FLAT : ((rows_out <= 128 || half_empty_last_block) ? MID : TALL);
+}
+
+struct RowPart {
+  int geo = TALL;
+  uint32_t row0 = 0, rows = 0, row_blocks = 0;
+};
+
+// Parts (round 4): with U = ceil(rows / 64) units, U = 4a + 1 (257-320, 513-576, 1025-1088, ... rows) is 256 a rows in the
+// 256-row geometry plus a last part of 1-64 rows — as a 16-row strip of the last 256-row block if it is at most 16 rows
+// (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry; U = 3 (129-192 rows) is
+// 128 rows in the 128-row geometry plus the last 1-64.  Returns the number of parts (0: the operator stays whole).
+inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2]) {
+  const uint32_t units = (rows + 63) / 64;
+  int np = 0;
+  if (units >= 5 && units % 4 == 1) {
+    const uint32_t full = 256 * (units / 4), rest = rows - full;
+    if (rest <= 16 && allow_strip) {
+      if (full > 256) out[np++] = RowPart{TALL, 0, full - 256, full / 256 - 1};
+      out[np++] = RowPart{TALL_STRIP, full - 256, 256 + rest, 1};
+    } else {
+      out[np++] = RowPart{TALL, 0, full, full / 256};
+      out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, full, rest, 1};
+    }
+  } else if (units == 3) {
+    const uint32_t rest = rows - 128;
+    out[np++] = RowPart{MID, 0, 128, 1};
+    out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, 128, rest, 1};
+  }
+  return np;
+}
+
+// rows of a tile of each geometry (the strip: 256 + 16)
+inline uint32_t tile_rows(int geo) {
+  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272};
+  return bm[geo];
+}
+
 struct GeoModel {
   int bn;            // columns per tile
   int per_cu;        // resident workgroups per CU

@@ -82,6 +82,54 @@ int main() {
     const Choice none = choose(own, num_own, alt, 0, M, nk, cus);
     CHECK(none.alt < 0 && none.primary_cols == M, "no alternates: nothing to choose");
   }
+  // ---- rows: own geometry and parts
+  {
+    struct ExpectRows { uint32_t rows; int own; int np; int g0, g1; };
+    const ExpectRows rows_table[] = {
+        {16, FLAT, 0, -1, -1},   {64, FLAT, 0, -1, -1},      {65, MID, 0, -1, -1},         {128, MID, 0, -1, -1},
+        {129, TALL, 2, MID, WIDE32},  {160, TALL, 2, MID, WIDE32}, {161, TALL, 2, MID, WIDE},  {192, TALL, 2, MID, WIDE},
+        {193, TALL, 0, -1, -1},  {255, TALL, 0, -1, -1},     {256, TALL, 0, -1, -1},       {257, MID, 1, TALL_STRIP, -1},
+        {272, MID, 1, TALL_STRIP, -1}, {273, MID, 2, TALL, WIDE32}, {288, MID, 2, TALL, WIDE32}, {289, MID, 2, TALL, WIDE},
+        {320, MID, 2, TALL, WIDE}, {321, MID, 0, -1, -1},     {384, MID, 0, -1, -1},        {385, TALL, 0, -1, -1},
+        {512, TALL, 0, -1, -1},  {513, MID, 2, TALL, TALL_STRIP}, {528, MID, 2, TALL, TALL_STRIP}, {529, MID, 2, TALL, WIDE32},
+        {576, MID, 2, TALL, WIDE}, {640, MID, 0, -1, -1},     {1024, TALL, 0, -1, -1},      {1025, MID, 2, TALL, TALL_STRIP},
+        {1088, MID, 2, TALL, WIDE},
+    };
+    for (const ExpectRows& e : rows_table) {
+      RowPart rp[2];
+      const int np = row_parts(e.rows, true, rp);
+      CHECK(own_geometry(e.rows) == e.own, "rows %u: own geometry %d", e.rows, own_geometry(e.rows));
+      CHECK(np == e.np && (np < 1 || rp[0].geo == e.g0) && (np < 2 || rp[1].geo == e.g1), "rows %u: %d parts (%d, %d)", e.rows, np,
+            np > 0 ? rp[0].geo : -1, np > 1 ? rp[1].geo : -1);
+    }
+    for (uint32_t rows = 1; rows <= 4200; ++rows) {
+      for (int strip = 0; strip < 2; ++strip) {
+        RowPart rp[2];
+        const int np = row_parts(rows, strip != 0, rp);
+        CHECK(np >= 0 && np <= 2, "rows %u: %d parts", rows, np);
+        if (np == 0) continue;
+        // the parts tile [0, rows) without gap or overlap, each starts on a row block of its own geometry, none is empty
+        uint32_t next = 0, padded = 0;
+        for (int i = 0; i < np; ++i) {
+          CHECK(rp[i].row0 == next && rp[i].rows > 0, "rows %u part %d: row0 %u rows %u", rows, i, rp[i].row0, rp[i].rows);
+          const uint32_t bm = tile_rows(rp[i].geo);
+          CHECK(rp[i].rows <= rp[i].row_blocks * bm && rp[i].rows > (rp[i].row_blocks - 1) * bm, "rows %u part %d: %u rows in %u blocks of %u",
+                rows, i, rp[i].rows, rp[i].row_blocks, bm);
+          CHECK(rp[i].row0 % 64 == 0, "rows %u part %d starts at %u", rows, i, rp[i].row0);
+          CHECK(rp[i].geo != TALL_STRIP || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 256 && rp[i].rows <= 272), "rows %u: strip of %u rows",
+                rows, rp[i].rows);
+          CHECK(i == 0 || rp[i].geo == TALL_STRIP || rp[i].rows <= 64, "rows %u: last part of %u rows", rows, rp[i].rows);
+          next += rp[i].rows;
+          padded += rp[i].row_blocks * (rp[i].geo == TALL_STRIP ? 256 + 16 * ((rp[i].rows - 256 + 15) / 16) : bm);
+        }
+        CHECK(next == rows, "rows %u: parts cover %u", rows, next);
+        // what parts are for: never more padding than the operator kept whole in its own geometry, and at most 63 padded rows
+        const uint32_t own_bm = tile_rows(own_geometry(rows));
+        const uint32_t whole = (rows + own_bm - 1) / own_bm * own_bm;
+        CHECK(padded <= whole && padded - rows < 64, "rows %u: %u padded rows in parts, %u whole", rows, padded, whole);
+      }
+    }
+  }
   std::printf("column_plan_check: %d failures\n", failures);
   return failures == 0 ? 0 : 1;
 }

@@ -5,8 +5,11 @@ feeds it the handle's geometries and follows its choice.  tests/cpp/column_plan_
 sizes that were measured on the MI355X (profiles/r04_geometry_by_columns.log), the model against those measurements, and —
 over 200 000 random shapes — the invariants run() relies on: kept columns are whole tiles of every primary geometry, an
 alternate is named exactly when columns are left over, and the plan never deviates from the operator's own geometry for
-less than 5 % of modelled gain.  What the planned launches compute is tests/test_apply_gpu.py's subject
-(test_column_plan_gives_the_bits_of_the_own_geometry)."""
+less than 5 % of modelled gain.  The same header holds the ROW side of the launch plan — the operator's own geometry by
+rows and the parts it is cut into (create_from_matrix follows it): checked at the sizes DESIGN.md names and, for every row
+count up to 4 200, that the parts tile the rows without gap or overlap, start on row blocks, never pad more than the whole
+operator would and never more than 63 rows.  What the planned launches compute is tests/test_apply_gpu.py's subject
+(test_column_plan_gives_the_bits_of_the_own_geometry, test_parts_give_the_bits_of_the_whole_operator)."""
 import os
 import subprocess
 
