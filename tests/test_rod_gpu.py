@@ -182,6 +182,27 @@ def test_fused_step_on_the_xcd_grouped_tile_walk(sri):
     assert update.view(torch.float64).item() == (tips - tips_prev).abs().max().item()
 
 
+@pytest.mark.parametrize("n,rods", [(256, 300), (257, 500), (129, 77), (300, 1000)])
+def test_rod_solve_is_the_same_under_the_column_plan(sri, n, rods, monkeypatch):
+    """A whole solve (predictor, prolongation, fused steps, closing integration, position integration) on a batch that is a
+    fraction of a round of tiles: with every launch in the operator's own geometry and with whatever the column plan picks — a
+    finer geometry for every fused step and every apply here — Q, R, the iteration count and the last update are identical
+    (every geometry computes the same chains of fused multiply-adds; the convergence monitor is a maximum)."""
+    import torch
+
+    qe = torch.from_numpy(_qe_batch(rods, seed=n)).cuda()
+    out = []
+    for planned in ("0", "1"):
+        monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", planned)         # read when the handles are created
+        rod = sri.RodIntegrator(n)
+        Q, R = rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
+        torch.cuda.synchronize()
+        out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update, rod.last_apply_kernel))
+    assert out[0][4] != out[1][4], (out[0][4], out[1][4])             # (the plan did pick something else)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert out[0][2:4] == out[1][2:4]
+
+
 def test_large_batch_properties(sri):
     """N=256, 4096 rods: too many for the dense oracle — check invariants of the exact solution instead."""
     import torch
