@@ -1719,7 +1719,15 @@ using GeoWide32 = Geo<1, 4, 2, 4, 2>;
 // with those r rows riding along (+ 2 MFMAs per 32 and two fragment reads per k pair and wave): no second pass over the panel
 using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5 };
+// BM 96 x BN 128, 4 waves side by side (96 x 32 each: six row tiles, two column tiles), two-slot ring (56 KiB, 2 WG per CU): operators
+// of 65-96 rows as ONE row block of their own height instead of a 128-row block that is a quarter to a half padding.  Plain and
+// rank-1-epilogue launches (the fused step and sri_apply_many keep the 128-row geometry: its side buffers want 128 rows).
+#ifndef SRI_G96_STAGES
+#define SRI_G96_STAGES 2
+#endif
+using Geo96 = Geo<1, 4, 6, 2, SRI_G96_STAGES>;
+
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6 };
 
 }  // namespace sri
 

@@ -31,6 +31,12 @@ static int dispatch_wide(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipS
               : launch<GeoWide, true, false, false>(args, col_tiles, dev, cus, cap, stream);
 }
 
+int prepare_g96(int dev) { return prepare_wide<Geo96>(dev); }
+int dispatch_g96(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<Geo96>(h, args, rank1, stream); }
+void pack_g96(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+              std::vector<double>& out) {
+  pack_operator<Geo96>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
 int prepare_wide64(int dev) { return prepare_wide<GeoWide>(dev); }
 int prepare_wide32(int dev) { return prepare_wide<GeoWide32>(dev); }
 int dispatch_wide64(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<GeoWide>(h, args, rank1, stream); }

@@ -79,6 +79,11 @@ STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256
 
 
 @pytest.mark.parametrize("n,which,M,geometry", [
+    (96, 0, 300, "<96x128,dma>"),    # 65 ... 96 rows (round 4): one 96-row block instead of a 128-row one
+    (66, 0, 515, "<96x128,dma>"),
+    (90, 1, 333, "<96x128,dma>"),    # 89 rows: k tail, the last wave's rows beyond 89 do not exist
+    (97, 2, 130, "<96x128,dma>"),    # Dn_NN of a 97-node grid: 96 rows
+    (98, 0, 200, "<128x128,dma>"),
     (256, 0, 300, "<256x128,dma>"),  # a full 256-row block
     (257, 0, 300, STRIP1),           # 257 ... 272 rows (round 4): ONE launch, the last 1-16 rows as a strip of the 256-row block
     (258, 1, 515, STRIP1),           # 257 rows of an integration operator
@@ -124,7 +129,7 @@ def test_mfma_layout_exact_integers(sri):
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
     Asymmetric data, as cdna_hip_programming.md §3 asks."""
     rng = np.random.default_rng(7)
-    for rows, M in [(16, 16), (64, 70), (48, 5), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
+    for rows, M in [(16, 16), (64, 70), (48, 5), (96, 130), (80, 200), (95, 67), (65, 129), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
@@ -219,7 +224,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
     import os
     import torch
 
-    for n, which, M, ld_extra in [(300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
+    for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
                                   (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
@@ -243,7 +248,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert (">+<" in outs[0][2] or "256+16" in outs[0][2]) and ">+<" not in outs[1][2] and "256+16" not in outs[1][2], (outs[0][2], outs[1][2])
+        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or "96x128" in outs[0][2]) and ">+<" not in outs[1][2] and "256+16" not in outs[1][2] and "96x128" not in outs[1][2], (outs[0][2], outs[1][2])
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
         assert torch.equal(outs[0][1], outs[0][0][:, 0])
         if which == 1:
@@ -350,7 +355,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     assert mixed >= 2 and finer >= 10, (mixed, finer)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 129, 257, 273, 289, 513])
+@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 81, 97, 90, 129, 257, 273, 289, 513])
 @pytest.mark.parametrize("planned", [False, True])
 def test_integrate_matches_oracle(sri, oracle, n, planned):
     """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T).  Both forms of the initial-value term: folded into
