@@ -1727,7 +1727,11 @@ using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
 #endif
 using Geo96 = Geo<1, 4, 6, 2, SRI_G96_STAGES>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6 };
+// BM 192 x BN 64, 2 x 2 waves of 96 x 32, two-slot ring (64 KiB, 2 WG per CU): operators of 161-192 rows in ONE pass over the panel
+// (before: 128 rows in the 128-row geometry + a second launch for the rest; N = 192: 0.75 -> 0.80 of the peak, 191 rows +15 %)
+using Geo192 = Geo<2, 2, 6, 2, 2>;
+
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7 };
 
 }  // namespace sri
 
