@@ -1731,7 +1731,11 @@ using Geo96 = Geo<1, 4, 6, 2, SRI_G96_STAGES>;
 // (before: 128 rows in the 128-row geometry + a second launch for the rest; N = 192: 0.75 -> 0.80 of the peak, 191 rows +15 %)
 using Geo192 = Geo<2, 2, 6, 2, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7 };
+// BM 160 x BN 64, four waves side by side (160 x 16 each: ten row tiles, one column tile), two-slot ring (56 KiB, 2 WG per CU):
+// operators of 129-160 rows in ONE pass (before: 128 rows + a second launch at the copy rate; N = 160: 0.68 -> 0.77 of the peak)
+using Geo160 = Geo<1, 4, 10, 1, 2>;
+
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8 };
 
 }  // namespace sri
 

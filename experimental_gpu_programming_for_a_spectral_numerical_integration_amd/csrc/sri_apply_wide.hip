@@ -43,6 +43,12 @@ void pack_g192(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32
                std::vector<double>& out) {
   pack_operator<Geo192>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
 }
+int prepare_g160(int dev) { return prepare_wide<Geo160>(dev); }
+int dispatch_g160(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<Geo160>(h, args, rank1, stream); }
+void pack_g160(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+               std::vector<double>& out) {
+  pack_operator<Geo160>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
 int prepare_wide64(int dev) { return prepare_wide<GeoWide>(dev); }
 int prepare_wide32(int dev) { return prepare_wide<GeoWide32>(dev); }
 int dispatch_wide64(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<GeoWide>(h, args, rank1, stream); }

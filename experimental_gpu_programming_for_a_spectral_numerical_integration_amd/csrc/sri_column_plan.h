@@ -26,7 +26,7 @@ namespace sri {
 namespace plan {
 
 // ids as sri::GeoId (sri_apply_kernel.h)
-enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, GEO_COUNT = 8 };
+enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, GEO_COUNT = 9 };
 
 // ---- rows: the operator's own geometry, and the parts it is cut into (sri_apply.hip's create_from_matrix) ----------------------
 // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry is
@@ -41,11 +41,12 @@ struct RowPart {
   uint32_t row0 = 0, rows = 0, row_blocks = 0;
 };
 
-// Parts (round 4): 65-96 rows are ONE part in the 96 x 128 geometry, 161-192 rows one in the 192 x 64 geometry (plain and
-// rank-1-epilogue launches; the fused step and sri_apply_many stay on the operator's own 128- / 256-row geometry).  With U = ceil(rows / 64) units, U = 4a + 1 (257-320, 513-576, 1025-1088, ... rows) is 256 a rows in the
+// Parts (round 4): 65-96 rows are ONE part in the 96 x 128 geometry, 129-160 rows one in the 160 x 64 geometry, 161-192 rows
+// one in the 192 x 64 geometry — a row block of the operator's own height (plain and rank-1-epilogue launches; the fused step and
+// sri_apply_many stay on the operator's own 128- / 256-row geometry).  With U = ceil(rows / 64) units, U = 4a + 1 (257-320, 513-576, 1025-1088, ... rows) is 256 a rows in the
 // 256-row geometry plus a last part of 1-64 rows — as a 16-row strip of the last 256-row block if it is at most 16 rows
-// (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry; U = 3 (129-192 rows) is
-// 128 rows in the 128-row geometry plus the last 1-32 (129-160 rows; above, the 192-row block is faster).  Returns the number of parts (0: the operator stays whole).
+// (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry.  Returns the number of parts
+// (0: the operator stays whole).
 inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2]) {
   const uint32_t units = (rows + 63) / 64;
   int np = 0;
@@ -53,7 +54,11 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2]) {
     out[np++] = RowPart{G96, 0, rows, 1};
     return np;
   }
-  if (rows > 160 && rows <= 192) {                                 // one row block of 192 (192 x 64 tiles): one pass over the panel
+  if (rows > 128 && rows <= 160) {                                 // one row block of 160 (160 x 64 tiles) ...
+    out[np++] = RowPart{G160, 0, rows, 1};
+    return np;
+  }
+  if (rows > 160 && rows <= 192) {                                 // ... or of 192 (192 x 64 tiles): one pass over the panel
     out[np++] = RowPart{G192, 0, rows, 1};
     return np;
   }
@@ -66,17 +71,13 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2]) {
       out[np++] = RowPart{TALL, 0, full, full / 256};
       out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, full, rest, 1};
     }
-  } else if (units == 3) {
-    const uint32_t rest = rows - 128;
-    out[np++] = RowPart{MID, 0, 128, 1};
-    out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, 128, rest, 1};
   }
   return np;
 }
 
 // rows of a tile of each geometry (the strip: 256 + 16)
 inline uint32_t tile_rows(int geo) {
-  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192};
+  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160};
   return bm[geo];
 }
 
@@ -97,7 +98,8 @@ inline const GeoModel& model(int geo) {
       /* WIDE32 32 x 256 */ {256, 2, {1.30, 2.30, 0, 0, 0}, 1.15, 0.0},
       /* STRIP 272 x 128 */ {128, 1, {4.30, 0, 0, 0, 0}, 4.30, 0.0},
       /* G96    96 x 128 */ {128, 2, {2.00, 3.80, 0, 0, 0}, 1.90, 0.0},    // (N = 96: 10.7 rounds in 244.7 us — the memory system's pace, not the MFMA pipe's)
-      /* G192  192 x 64  */ {64, 2, {2.00, 3.80, 0, 0, 0}, 1.90, 0.0},
+      /* G192  192 x 64  */ {64, 2, {1.70, 3.20, 0, 0, 0}, 1.60, 0.0},     // (N = 192: 10.7 rounds in 408.5 us)
+      /* G160  160 x 64  */ {64, 2, {1.50, 2.80, 0, 0, 0}, 1.40, 0.0},     // (N = 160: 12.8 rounds in 355.6 us)
   };
   return table[geo];
 }

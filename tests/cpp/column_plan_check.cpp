@@ -87,7 +87,7 @@ int main() {
     struct ExpectRows { uint32_t rows; int own; int np; int g0, g1; };
     const ExpectRows rows_table[] = {
         {16, FLAT, 0, -1, -1},   {64, FLAT, 0, -1, -1},      {65, MID, 1, G96, -1},        {96, MID, 1, G96, -1},      {97, MID, 0, -1, -1},      {128, MID, 0, -1, -1},
-        {129, TALL, 2, MID, WIDE32},  {160, TALL, 2, MID, WIDE32}, {161, TALL, 1, G192, -1},   {192, TALL, 1, G192, -1},
+        {129, TALL, 1, G160, -1},     {160, TALL, 1, G160, -1}, {161, TALL, 1, G192, -1},   {192, TALL, 1, G192, -1},
         {193, TALL, 0, -1, -1},  {255, TALL, 0, -1, -1},     {256, TALL, 0, -1, -1},       {257, MID, 1, TALL_STRIP, -1},
         {272, MID, 1, TALL_STRIP, -1}, {273, MID, 2, TALL, WIDE32}, {288, MID, 2, TALL, WIDE32}, {289, MID, 2, TALL, WIDE},
         {320, MID, 2, TALL, WIDE}, {321, MID, 0, -1, -1},     {384, MID, 0, -1, -1},        {385, TALL, 0, -1, -1},
