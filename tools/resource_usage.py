@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 txt = open(os.path.join(ROOT, "build/asm/resource_usage.txt")).read()
 isa = open(os.path.join(ROOT, "build/asm/sri_apply-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 GEO = {"1,4,4,1,3,0": "flat 64x64   Geo<1,4,4,1,3>", "2,2,4,4,2,0": "mid  128x128 Geo<2,2,4,4,2>", "4,2,4,4,3,0": "tall 256x128 Geo<4,2,4,4,3>",
-       "1,4,4,4,2,0": "wide 64x256  Geo<1,4,4,4,2>", "1,4,2,4,2,0": "wide 32x256  Geo<1,4,2,4,2>", "4,2,4,4,3,1": "strip 272x128 Geo<4,2,4,4,3,1>"}
+       "1,4,4,4,2,0": "wide 64x256  Geo<1,4,4,4,2>", "1,4,2,4,2,0": "wide 32x256  Geo<1,4,2,4,2>", "4,2,4,4,3,1": "strip 272x128 Geo<4,2,4,4,3,1>",
+       "1,4,6,2,2,0": "g96  96x128  Geo<1,4,6,2,2>", "1,4,10,1,2,0": "g160 160x64  Geo<1,4,10,1,2>", "2,2,6,2,2,0": "g192 192x64  Geo<2,2,6,2,2>"}
 SCR, OCC = r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
 out = ["# Register / spill / occupancy report of every shipped variant of sri::apply_kernel (csrc/sri_apply.hip).",
        "# `make -C <pkg>/csrc asm` (hipcc -Rpass-analysis=kernel-resource-usage, --offload-arch=gfx950) + tools/resource_usage.py.",
@@ -24,8 +25,8 @@ out = ["# Register / spill / occupancy report of every shipped variant of sri::a
 for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
     name = b.split("\n")[0].split(" ")[0]
     g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
-    mg = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEE", name)
-    m = re.search(r"GeoILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi\dEEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)", name)
+    mg = re.search(r"GeoILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEE", name)
+    m = re.search(r"GeoILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+EEELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)", name)
     if mg is None or m is None:
         continue
     i = isa.index(name + ":")
