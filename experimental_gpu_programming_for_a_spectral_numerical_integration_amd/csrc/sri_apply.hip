@@ -164,7 +164,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     int np = 0;
     if (square && !(no_parts && no_parts[0] == '1')) {
       plan::RowPart rp[2];
-      np = plan::row_parts(rows, !(no_strip && no_strip[0] == '1'), rp);   // (sri_column_plan.h; tests/cpp/column_plan_check.cpp)
+      const char* no_ext = std::getenv("SRI_APPLY_PARTS_EXT");       // A/B: =0 keeps 256 a + 65 ... 96 / 129 ... 192 rows whole
+      np = plan::row_parts(rows, !(no_strip && no_strip[0] == '1'), rp, !(no_ext && no_ext[0] == '0'));   // (sri_column_plan.h; tests/cpp/column_plan_check.cpp)
       for (int i = 0; i < np; ++i) {
         h->parts[i].geo = rp[i].geo;
         h->parts[i].row0 = rp[i].row0;

@@ -41,36 +41,35 @@ struct RowPart {
   uint32_t row0 = 0, rows = 0, row_blocks = 0;
 };
 
-// Parts (round 4): 65-96 rows are ONE part in the 96 x 128 geometry, 129-160 rows one in the 160 x 64 geometry, 161-192 rows
+// Parts (round 4), by the rows behind the last full 256-row block: 65-96 rows are ONE part in the 96 x 128 geometry, 129-160 rows one in the 160 x 64 geometry, 161-192 rows
 // one in the 192 x 64 geometry — a row block of the operator's own height (plain and rank-1-epilogue launches; the fused step and
 // sri_apply_many stay on the operator's own 128- / 256-row geometry).  With U = ceil(rows / 64) units, U = 4a + 1 (257-320, 513-576, 1025-1088, ... rows) is 256 a rows in the
 // 256-row geometry plus a last part of 1-64 rows — as a 16-row strip of the last 256-row block if it is at most 16 rows
 // (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry.  Returns the number of parts
 // (0: the operator stays whole).
-inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2]) {
-  const uint32_t units = (rows + 63) / 64;
+inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool extended = true) {
   int np = 0;
-  if (rows > 64 && rows <= 96) {                                   // one row block of 96 instead of a 128-row block (a "part" of one)
-    out[np++] = RowPart{G96, 0, rows, 1};
+  // the rows behind the last full 256-row block: 1 ... 256 of them (all of the operator's rows when it has at most 256)
+  const uint32_t full = rows > 256 ? (rows - 1) / 256 * 256 : 0, rest = rows - full;
+  int last = -1;                                                   // geometry of a last part of `rest` rows (-1: none)
+  if (rest > 64 && rest <= 96) last = G96;                         // one row block of 96 ...
+  else if (rest > 128 && rest <= 160) last = G160;                 // ... of 160 (160 x 64 tiles) ...
+  else if (rest > 160 && rest <= 192) last = G192;                 // ... or of 192 (192 x 64 tiles)
+  if (full == 0) {                                                 // at most 256 rows: one block of the operator's own height, in one pass
+    if (last >= 0) out[np++] = RowPart{last, 0, rows, 1};
     return np;
   }
-  if (rows > 128 && rows <= 160) {                                 // one row block of 160 (160 x 64 tiles) ...
-    out[np++] = RowPart{G160, 0, rows, 1};
-    return np;
-  }
-  if (rows > 160 && rows <= 192) {                                 // ... or of 192 (192 x 64 tiles): one pass over the panel
-    out[np++] = RowPart{G192, 0, rows, 1};
-    return np;
-  }
-  if (units >= 5 && units % 4 == 1) {
-    const uint32_t full = 256 * (units / 4), rest = rows - full;
-    if (rest <= 16 && allow_strip) {
-      if (full > 256) out[np++] = RowPart{TALL, 0, full - 256, full / 256 - 1};
-      out[np++] = RowPart{TALL_STRIP, full - 256, 256 + rest, 1};
-    } else {
-      out[np++] = RowPart{TALL, 0, full, full / 256};
-      out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, full, rest, 1};
-    }
+  if (rest <= 16 && allow_strip) {
+    if (full > 256) out[np++] = RowPart{TALL, 0, full - 256, full / 256 - 1};
+    out[np++] = RowPart{TALL_STRIP, full - 256, 256 + rest, 1};
+  } else if (rest <= 64) {
+    out[np++] = RowPart{TALL, 0, full, full / 256};
+    out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, full, rest, 1};
+  } else if (last >= 0 && extended) {
+    // 256 a + 65 ... 96 / 129 ... 192 rows: instead of three 128-row blocks for two and a bit, or a 256-row block that is half to
+    // three quarters full — the 256-row geometry for the full blocks, the rest in its own height (a second pass over the panel)
+    out[np++] = RowPart{TALL, 0, full, full / 256};
+    out[np++] = RowPart{last, full, rest, 1};
   }
   return np;
 }

@@ -90,9 +90,10 @@ int main() {
         {129, TALL, 1, G160, -1},     {160, TALL, 1, G160, -1}, {161, TALL, 1, G192, -1},   {192, TALL, 1, G192, -1},
         {193, TALL, 0, -1, -1},  {255, TALL, 0, -1, -1},     {256, TALL, 0, -1, -1},       {257, MID, 1, TALL_STRIP, -1},
         {272, MID, 1, TALL_STRIP, -1}, {273, MID, 2, TALL, WIDE32}, {288, MID, 2, TALL, WIDE32}, {289, MID, 2, TALL, WIDE},
-        {320, MID, 2, TALL, WIDE}, {321, MID, 0, -1, -1},     {384, MID, 0, -1, -1},        {385, TALL, 0, -1, -1},
+        {320, MID, 2, TALL, WIDE}, {321, MID, 2, TALL, G96},  {352, MID, 2, TALL, G96},   {353, MID, 0, -1, -1},   {384, MID, 0, -1, -1},        {385, TALL, 2, TALL, G160},
+        {416, TALL, 2, TALL, G160}, {417, TALL, 2, TALL, G192}, {448, TALL, 2, TALL, G192}, {449, TALL, 0, -1, -1},
         {512, TALL, 0, -1, -1},  {513, MID, 2, TALL, TALL_STRIP}, {528, MID, 2, TALL, TALL_STRIP}, {529, MID, 2, TALL, WIDE32},
-        {576, MID, 2, TALL, WIDE}, {640, MID, 0, -1, -1},     {1024, TALL, 0, -1, -1},      {1025, MID, 2, TALL, TALL_STRIP},
+        {576, MID, 2, TALL, WIDE}, {600, MID, 2, TALL, G96},  {640, MID, 0, -1, -1},     {700, TALL, 2, TALL, G192},     {1024, TALL, 0, -1, -1},      {1025, MID, 2, TALL, TALL_STRIP},
         {1088, MID, 2, TALL, WIDE},
     };
     for (const ExpectRows& e : rows_table) {
@@ -118,7 +119,7 @@ int main() {
           CHECK(rp[i].row0 % 64 == 0, "rows %u part %d starts at %u", rows, i, rp[i].row0);
           CHECK(rp[i].geo != TALL_STRIP || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 256 && rp[i].rows <= 272), "rows %u: strip of %u rows",
                 rows, rp[i].rows);
-          CHECK(i == 0 || rp[i].geo == TALL_STRIP || rp[i].rows <= 64, "rows %u: last part of %u rows", rows, rp[i].rows);
+          CHECK(i == 0 || rp[i].geo == TALL_STRIP || rp[i].rows <= 192, "rows %u: last part of %u rows", rows, rp[i].rows);
           next += rp[i].rows;
           padded += rp[i].row_blocks * (rp[i].geo == TALL_STRIP ? 256 + 16 * ((rp[i].rows - 256 + 15) / 16) : bm);
         }

@@ -94,12 +94,18 @@ STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256
     (320, 0, 700, WIDE_TALL),
     (321, 1, 260, WIDE_TALL),        # the integration operator of a 321-node grid: 320 rows
     (384, 0, 129, "<128x128,dma>"),  # 321 ... 384 rows: three 128-row blocks instead of two 256-row ones (round 3)
-    (385, 0, 200, "<256x128,dma>"),  # the last 256-row block is more than half full again
+    (352, 0, 200, "<256x128,dma>+<96x128,dma>"),    # 256 a + 65 ... 96 / 129 ... 192 rows (round 4): the full blocks in the 256-row geometry,
+    (385, 0, 200, "<256x128,dma>+<160x64,dma>"),    # ... the rest as a last part of its own height
+    (400, 2, 300, "<256x128,dma>+<160x64,dma>"),    # 399 rows, k tail
+    (448, 1, 515, "<256x128,dma>+<192x64,dma>"),    # 447 rows
+    (449, 0, 200, "<256x128,dma>"),  # the last 256-row block is three quarters full again
+    (700, 0, 140, "<256x128,dma>+<192x64,dma>"),    # ascending k: two row blocks + 188 rows
     (513, 0, 140, STRIPN),           # ascending k: one plain row block + the last block with its strip        # ascending-k builds of both parts, two row blocks + one row
     (560, 2, 150, WIDE_TALL),        # Dn_NN of a 560-node grid: 559 rows, ascending k with a k tail
     (640, 0, 140, "<128x128,dma>"),  # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
     (641, 1, 90, "<128x128,dma>"),   # 640 rows, paired order (integration operator)
-    (897, 0, 70, "<256x128,dma>"),
+    (897, 0, 70, "<256x128,dma>+<160x64,dma>"),
+    (960, 0, 70, "<256x128,dma>+<192x64,dma>"),
     (1025, 0, 2100, STRIPN),         # three row blocks + the last with one more row
     (1040, 0, 300, STRIPN),          # ... with sixteen
     (1041, 0, 300, THIN_TALL),      # four row blocks (XCD-grouped walk of the main part) + one row
@@ -131,7 +137,7 @@ def test_mfma_layout_exact_integers(sri):
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
     Asymmetric data, as cdna_hip_programming.md §3 asks."""
     rng = np.random.default_rng(7)
-    for rows, M in [(16, 16), (64, 70), (48, 5), (96, 130), (80, 200), (95, 67), (65, 129), (192, 70), (175, 131), (161, 64), (160, 70), (145, 129), (129, 65), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
+    for rows, M in [(16, 16), (64, 70), (48, 5), (96, 130), (80, 200), (95, 67), (65, 129), (192, 70), (175, 131), (161, 64), (160, 70), (145, 129), (129, 65), (400, 130), (447, 70), (352, 129), (330, 64), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
@@ -226,7 +232,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
     import os
     import torch
 
-    for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
+    for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
                                   (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
@@ -357,7 +363,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     assert mixed >= 2 and finer >= 10, (mixed, finer)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 81, 97, 90, 129, 145, 161, 150, 177, 193, 180, 257, 273, 289, 513])
+@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 81, 97, 90, 129, 145, 161, 150, 177, 193, 180, 257, 273, 289, 353, 417, 513])
 @pytest.mark.parametrize("planned", [False, True])
 def test_integrate_matches_oracle(sri, oracle, n, planned):
     """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T).  Both forms of the initial-value term: folded into
