@@ -216,7 +216,10 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       if (rc != SRI_OK) return fail(rc);
       h->num_parts = np;
       h->parts_name = h->parts_label.c_str();
-      h->parts_label_lean = h->parts_label + ",lean";
+      // (",lean": a part in a geometry that has lean twins took one — the 96 / 160 / 192-row blocks and the wide parts have none)
+      bool any_lean_twin = false;
+      for (int i = 0; i < np; ++i) any_lean_twin = any_lean_twin || h->parts[i].geo == GEO_TALL || h->parts[i].geo == GEO_MID || h->parts[i].geo == GEO_TALL_STRIP;
+      h->parts_label_lean = h->parts_label + (any_lean_twin ? ",lean" : "");
       h->parts_name_lean = h->parts_label_lean.c_str();
     }
   }
