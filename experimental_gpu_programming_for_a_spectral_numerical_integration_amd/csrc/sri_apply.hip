@@ -13,7 +13,7 @@
 namespace sri {
 
 static_assert(plan::FLAT == GEO_FLAT && plan::MID == GEO_MID && plan::TALL == GEO_TALL && plan::WIDE == GEO_WIDE &&
-              plan::WIDE32 == GEO_WIDE32 && plan::TALL_STRIP == GEO_TALL_STRIP && plan::G96 == GEO_96 && plan::G192 == GEO_192 && plan::G160 == GEO_160, "sri_column_plan.h uses GeoId's values");
+              plan::WIDE32 == GEO_WIDE32 && plan::TALL_STRIP == GEO_TALL_STRIP && plan::G96 == GEO_96 && plan::G192 == GEO_192 && plan::G160 == GEO_160 && plan::G224 == GEO_224, "sri_column_plan.h uses GeoId's values");
 
 static thread_local int g_last_hip_error = 0;
 void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
@@ -174,7 +174,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       }
     }
     if (np != 0) {
-      static const char* const geo_names[9] = {"<64x64,dma>", "<128x128,dma>", "<256x128,dma>", "<64x256,dma>", "<32x256,dma>", "<256+16x128,dma>", "<96x128,dma>", "<192x64,dma>", "<160x64,dma>"};
+      static const char* const geo_names[10] = {"<64x64,dma>", "<128x128,dma>", "<256x128,dma>", "<64x256,dma>", "<32x256,dma>", "<256+16x128,dma>", "<96x128,dma>", "<192x64,dma>", "<160x64,dma>", "<224x64,dma>"};
       const double* wf = (rows % BK != 0) ? w_host : nullptr;
       h->parts_label = "sri_apply_mfma_f64";
       for (int i = 0; i < np && rc == SRI_OK; ++i) {
@@ -187,6 +187,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
           case GEO_96: rc = prepare_g96(device); break;
           case GEO_192: rc = prepare_g192(device); break;
           case GEO_160: rc = prepare_g160(device); break;
+          case GEO_224: rc = prepare_g224(device); break;
           default: rc = prepare_strip(device); break;
         }
         if (rc != SRI_OK) break;
@@ -202,6 +203,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
             case GEO_96: pack_g96(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             case GEO_192: pack_g192(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             case GEO_160: pack_g160(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            case GEO_224: pack_g224(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             default: pack_strip(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
           }
           h->parts_label += (i == 0 ? "" : "+");
@@ -211,7 +213,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
         }
         if (hipMalloc(&part.d_apack, pk.size() * sizeof(double)) != hipSuccess) return fail(SRI_ENOMEM);
         if (hipMemcpy(part.d_apack, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(SRI_EHIP);
-        if (part.geo == GEO_WIDE || part.geo == GEO_WIDE32 || part.geo == GEO_96 || part.geo == GEO_192 || part.geo == GEO_160) h->parts_have_wide = true;
+        if (part.geo == GEO_WIDE || part.geo == GEO_WIDE32 || part.geo == GEO_96 || part.geo == GEO_192 || part.geo == GEO_160 || part.geo == GEO_224) h->parts_have_wide = true;
       }
       if (rc != SRI_OK) return fail(rc);
       h->num_parts = np;
@@ -386,7 +388,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
         a.row_blocks = part.row_blocks;
         a.tips = part.row0 == 0 ? cols_args.tips : nullptr;         // the tip node is row 0
         a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
-        const int prc = part.geo == GEO_160 ? dispatch_g160(h, a, rank1, stream)
+        const int prc = part.geo == GEO_224 ? dispatch_g224(h, a, rank1, stream)
+                        : part.geo == GEO_160 ? dispatch_g160(h, a, rank1, stream)
                         : part.geo == GEO_192 ? dispatch_g192(h, a, rank1, stream)
                         : part.geo == GEO_96 ? dispatch_g96(h, a, rank1, stream)
                         : part.geo == GEO_WIDE ? dispatch_wide64(h, a, rank1, stream)

@@ -28,6 +28,10 @@ int prepare_g192(int dev);
 int dispatch_g192(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream);
 void pack_g192(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                std::vector<double>& out);
+int prepare_g224(int dev);
+int dispatch_g224(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream);
+void pack_g224(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+               std::vector<double>& out);
 int prepare_g160(int dev);
 int dispatch_g160(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream);
 void pack_g160(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,

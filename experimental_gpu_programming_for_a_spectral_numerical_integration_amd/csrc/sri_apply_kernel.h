@@ -1729,13 +1729,16 @@ using Geo96 = Geo<1, 4, 6, 2, SRI_G96_STAGES>;
 
 // BM 192 x BN 64, 2 x 2 waves of 96 x 32, two-slot ring (64 KiB, 2 WG per CU): operators of 161-192 rows in ONE pass over the panel
 // (before: 128 rows in the 128-row geometry + a second launch for the rest; N = 192: 0.75 -> 0.80 of the peak, 191 rows +15 %)
-using Geo192 = Geo<2, 2, 6, 2, 2>;
+using Geo192 = Geo<2, 2, 6, 2, 2>;     // (four waves side by side, Geo<1,4,12,1,2>, were measured: -2.5 %)
+// BM 224 x BN 64, four waves side by side (224 x 16 each: fourteen row tiles — 112 accumulator registers), two-slot ring (72 KiB, 2 WG
+// per CU): operators of 193-224 rows, for which a 256-row block is 75-87 % full (N = 224: 0.69 -> 0.80 of the peak, N = 200 +18 %)
+using Geo224 = Geo<1, 4, 14, 1, 2>;
 
 // BM 160 x BN 64, four waves side by side (160 x 16 each: ten row tiles, one column tile), two-slot ring (56 KiB, 2 WG per CU):
 // operators of 129-160 rows in ONE pass (before: 128 rows + a second launch at the copy rate; N = 160: 0.68 -> 0.77 of the peak)
 using Geo160 = Geo<1, 4, 10, 1, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8 };
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9 };
 
 }  // namespace sri
 

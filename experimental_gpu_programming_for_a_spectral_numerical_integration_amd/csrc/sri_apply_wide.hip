@@ -1,4 +1,5 @@
-// sri_apply_wide.hip — the 64 x 256 and 32 x 256 geometries of an operator's last part (GeoWide, GeoWide32): plain and rank-1-epilogue variants
+// sri_apply_wide.hip — the 64 x 256 and 32 x 256 geometries of an operator's last part (GeoWide, GeoWide32) and the row blocks of an
+// operator's own height (Geo96, Geo160, Geo192, Geo224): plain and rank-1-epilogue variants
 #include "sri_apply_kernel.h"
 #include "sri_apply_geometries.h"
 
@@ -42,6 +43,12 @@ int dispatch_g192(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t
 void pack_g192(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                std::vector<double>& out) {
   pack_operator<Geo192>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
+int prepare_g224(int dev) { return prepare_wide<Geo224>(dev); }
+int dispatch_g224(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<Geo224>(h, args, rank1, stream); }
+void pack_g224(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+               std::vector<double>& out) {
+  pack_operator<Geo224>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
 }
 int prepare_g160(int dev) { return prepare_wide<Geo160>(dev); }
 int dispatch_g160(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream) { return dispatch_wide<Geo160>(h, args, rank1, stream); }

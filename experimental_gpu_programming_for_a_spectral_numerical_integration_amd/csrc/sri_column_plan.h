@@ -26,7 +26,7 @@ namespace sri {
 namespace plan {
 
 // ids as sri::GeoId (sri_apply_kernel.h)
-enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, GEO_COUNT = 9 };
+enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, G224 = 9, GEO_COUNT = 10 };
 
 // ---- rows: the operator's own geometry, and the parts it is cut into (sri_apply.hip's create_from_matrix) ----------------------
 // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry is
@@ -42,7 +42,7 @@ struct RowPart {
 };
 
 // Parts (round 4), by the rows behind the last full 256-row block: 65-96 rows are ONE part in the 96 x 128 geometry, 129-160 rows one in the 160 x 64 geometry, 161-192 rows
-// one in the 192 x 64 geometry — a row block of the operator's own height (plain and rank-1-epilogue launches; the fused step and
+// one in the 192 x 64 geometry, 193-224 rows (alone) one in the 224 x 64 geometry — a row block of the operator's own height (plain and rank-1-epilogue launches; the fused step and
 // sri_apply_many stay on the operator's own 128- / 256-row geometry).  With U = ceil(rows / 64) units, U = 4a + 1 (257-320, 513-576, 1025-1088, ... rows) is 256 a rows in the
 // 256-row geometry plus a last part of 1-64 rows — as a 16-row strip of the last 256-row block if it is at most 16 rows
 // (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry.  Returns the number of parts
@@ -56,6 +56,7 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
   else if (rest > 128 && rest <= 160) last = G160;                 // ... of 160 (160 x 64 tiles) ...
   else if (rest > 160 && rest <= 192) last = G192;                 // ... or of 192 (192 x 64 tiles)
   if (full == 0) {                                                 // at most 256 rows: one block of the operator's own height, in one pass
+    if (rest > 192 && rest <= 224) last = G224;                    // (behind full blocks a 256-row block that is 75-87 % full does as well)
     if (last >= 0) out[np++] = RowPart{last, 0, rows, 1};
     return np;
   }
@@ -76,7 +77,7 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
 
 // rows of a tile of each geometry (the strip: 256 + 16)
 inline uint32_t tile_rows(int geo) {
-  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160};
+  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160, 224};
   return bm[geo];
 }
 
@@ -99,6 +100,7 @@ inline const GeoModel& model(int geo) {
       /* G96    96 x 128 */ {128, 2, {2.00, 3.80, 0, 0, 0}, 1.90, 0.0},    // (N = 96: 10.7 rounds in 244.7 us — the memory system's pace, not the MFMA pipe's)
       /* G192  192 x 64  */ {64, 2, {1.70, 3.20, 0, 0, 0}, 1.60, 0.0},     // (N = 192: 10.7 rounds in 408.5 us)
       /* G160  160 x 64  */ {64, 2, {1.50, 2.80, 0, 0, 0}, 1.40, 0.0},     // (N = 160: 12.8 rounds in 355.6 us)
+      /* G224  224 x 64  */ {64, 2, {2.00, 3.75, 0, 0, 0}, 1.90, 0.0},     // (N = 224: 9.14 rounds in 480.7 us)
   };
   return table[geo];
 }

@@ -115,7 +115,9 @@ STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256
     (161, 0, 300, "<192x64,dma>"),   # 161 ... 192 rows (round 4): one 192-row block, 192 x 64 tiles — one pass over the panel
     (176, 0, 300, "<192x64,dma>"),
     (192, 2, 512, "<192x64,dma>"),   # 191 rows
-    (193, 0, 100, "<256x128,dma>"),
+    (193, 0, 100, "<224x64,dma>"),   # 193 ... 224 rows (round 4): one 224-row block (fourteen row tiles per wave)
+    (224, 2, 300, "<224x64,dma>"),   # 223 rows, k tail
+    (225, 0, 100, "<256x128,dma>"),
 ])
 def test_geometry_above_256_rows(sri, oracle, n, which, M, geometry):
     """Rows are tiled in blocks of 128 or 256; above 256 rows the handle takes the 128-row geometry wherever the last
@@ -137,7 +139,7 @@ def test_mfma_layout_exact_integers(sri):
     integers: all products and sums are exact in fp64, so the result must be bit-identical.
     Asymmetric data, as cdna_hip_programming.md §3 asks."""
     rng = np.random.default_rng(7)
-    for rows, M in [(16, 16), (64, 70), (48, 5), (96, 130), (80, 200), (95, 67), (65, 129), (192, 70), (175, 131), (161, 64), (160, 70), (145, 129), (129, 65), (400, 130), (447, 70), (352, 129), (330, 64), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
+    for rows, M in [(16, 16), (64, 70), (48, 5), (96, 130), (80, 200), (95, 67), (65, 129), (192, 70), (175, 131), (161, 64), (160, 70), (145, 129), (129, 65), (400, 130), (447, 70), (352, 129), (330, 64), (224, 70), (200, 129), (193, 65), (256, 130), (255, 67), (272, 64), (257, 130), (263, 129), (520, 100), (300, 77), (150, 300), (1024, 65), (17, 33), (31, 9), (241, 200), (129, 140), (15, 7), (1023, 130), (256, 1), (255, 1), (16, 1)]:
         A = np.asfortranarray(rng.integers(-7, 8, size=(rows, rows)).astype(np.float64))
         X = np.asfortranarray(rng.integers(-9, 10, size=(rows, M)).astype(np.float64))
         op = sri.SpectralApply(rows, matrix=A)
@@ -232,7 +234,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
     import os
     import torch
 
-    for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
+    for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (200, 0, 1000, 1), (209, 1, 515, 0), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
                                   (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
@@ -256,7 +258,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "96x128", "192x64", "160x64")), (outs[0][2], outs[1][2])
+        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64", "224x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "96x128", "192x64", "160x64", "224x64")), (outs[0][2], outs[1][2])
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
         assert torch.equal(outs[0][1], outs[0][0][:, 0])
         if which == 1:
@@ -363,7 +365,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     assert mixed >= 2 and finer >= 10, (mixed, finer)
 
 
-@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 81, 97, 90, 129, 145, 161, 150, 177, 193, 180, 257, 273, 289, 353, 417, 513])
+@pytest.mark.parametrize("n", [16, 64, 256, 300, 321, 17, 33, 65, 81, 97, 90, 129, 145, 161, 150, 177, 193, 180, 209, 225, 200, 257, 273, 289, 353, 417, 513])
 @pytest.mark.parametrize("planned", [False, True])
 def test_integrate_matches_oracle(sri, oracle, n, planned):
     """sri_integrate == main.cpp:172 batched: Dnn_inv (B - Dn_IN x_base^T).  Both forms of the initial-value term: folded into
