@@ -21,8 +21,8 @@ build/store_rate_probe: tools/store_rate_probe.hip
 	mkdir -p build && $(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
 GEOS := $(PKG)/csrc/sri_apply_tall.hip $(PKG)/csrc/sri_apply_mid.hip $(PKG)/csrc/sri_apply_strip.hip $(PKG)/csrc/sri_apply_flat.hip $(PKG)/csrc/sri_apply_wide.hip
-build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_apply_kernel.h $(PKG)/csrc/sri_apply_geometries.h $(GEOS) $(PKG)/csrc/sri_host_panels.hip $(PKG)/csrc/sri_host_pipeline.h $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
-	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Wno-pass-failed tools/apply_diag.hip $(GEOS) $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host_panels.hip $(PKG)/csrc/sri_host.cpp -o $@
+build/apply_diag: tools/apply_diag.hip $(PKG)/csrc/sri_apply.hip $(PKG)/csrc/sri_apply_kernel.h $(PKG)/csrc/sri_apply_geometries.h $(PKG)/csrc/sri_apply_geometry_impl.h $(GEOS) $(PKG)/csrc/sri_host_panels.hip $(PKG)/csrc/sri_host_pipeline.h $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host.cpp $(PKG)/csrc/sri_internal.h include/sri_capi.h
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -DSRI_DIAG -Wno-pass-failed tools/apply_diag.hip $(GEOS) $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_host_panels.hip $(PKG)/csrc/sri_host.cpp -o $@
 
 build/small_diag: tools/small_diag.hip $(PKG)/csrc/sri_apply_small.hip $(PKG)/csrc/sri_internal.h
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) tools/small_diag.hip -o $@

@@ -21,6 +21,8 @@ __all__ = [
     "SriError", "build_library", "library_path", "load_library",
     "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
     "SpectralApply", "RodIntegrator", "OP_DN", "OP_DNN_INV", "OP_DNN",
+    "OPT_COLUMN_PLAN", "OPT_LEAN_TAIL", "OPT_ROW_PARTS", "OPT_SMALL_KERNEL", "OPT_XCD_TILE_WALK", "OPT_HOST_COPY_THREADS",
+    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION",
 ]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +30,9 @@ _ROOT = os.path.dirname(_PKG)
 _LIB_NAME = "libsri_hip.so"
 
 OP_DN, OP_DNN_INV, OP_DNN = 0, 1, 2
+# sri_option (include/sri_capi.h)
+(OPT_COLUMN_PLAN, OPT_LEAN_TAIL, OPT_ROW_PARTS, OPT_SMALL_KERNEL, OPT_XCD_TILE_WALK, OPT_HOST_COPY_THREADS, OPT_HOST_BLOCK_COLUMNS,
+ OPT_MAX_WORKGROUPS, OPT_PLAN_CALIBRATION) = range(1, 10)
 
 _dp = C.POINTER(C.c_double)
 _lib: Optional[C.CDLL] = None
@@ -58,6 +63,9 @@ C_ABI = {
     "sri_apply_set_column_plan": (_int, [_vp, _int]),
     "sri_apply_set_host_copy_threads": (_int, [_vp, _int]),
     "sri_apply_set_host_memory_pinned": (_int, [_vp, _int]),
+    "sri_apply_set_option": (_int, [_vp, _int, C.c_long]),
+    "sri_apply_get_option": (_int, [_vp, _int, C.POINTER(C.c_long)]),
+    "sri_rod_set_option": (_int, [_vp, _int, C.c_long]),
     "sri_apply_destroy": (_int, [_vp]),
     "sri_rod_create": (_int, [C.POINTER(_vp), _u32, _int]),
     "sri_rod_destroy": (_int, [_vp]),
@@ -399,6 +407,15 @@ class SpectralApply:
         ``hipHostRegister``): copies then go straight from and to it.  A panel that is not is refused (``SRI_EINVAL``)."""
         _chk(load_library().sri_apply_set_host_memory_pinned(self._h, 1 if pinned else 0), "sri_apply_set_host_memory_pinned")
 
+    def set_option(self, option: int, value: int) -> None:
+        """``sri_apply_set_option``: any per-handle switch by its ``OPT_*`` number."""
+        _chk(load_library().sri_apply_set_option(self._h, int(option), int(value)), "sri_apply_set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_long()
+        _chk(load_library().sri_apply_get_option(self._h, int(option), C.byref(v)), "sri_apply_get_option")
+        return int(v.value)
+
     def set_max_workgroups(self, n: int) -> None:
         """Cap the persistent grid (0 = fill the chip): leaves CUs free for an overlapped collective."""
         _chk(load_library().sri_apply_set_max_workgroups(self._h, int(n)), "sri_apply_set_max_workgroups")
@@ -457,6 +474,10 @@ class RodIntegrator:
         N > 64; inside the one-launch pipeline a 32-node one for 32 < N <= 64 and a 16-node one for 16 < N <= 32.  False starts
         from q_init."""
         _chk(load_library().sri_rod_set_predictor(self._h, 1 if enable else 0), "sri_rod_set_predictor")
+
+    def set_option(self, option: int, value: int) -> None:
+        """``sri_rod_set_option``: an ``OPT_*`` switch on every apply handle inside this rod handle."""
+        _chk(load_library().sri_rod_set_option(self._h, int(option), int(value)), "sri_rod_set_option")
 
     @property
     def last_apply_kernel(self) -> str:

@@ -95,9 +95,12 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   h->geo = plan::own_geometry(rows_out);                          // (sri_column_plan.h)
   // (tiles of one or two k chunks: the fused step needs four side buffers, which the 256-row geometry's ring leaves no room for)
   if (!square && h->geo == GEO_TALL && (rows + BK - 1) / BK < 3) h->geo = GEO_MID;
-  // SRI_APPLY_FORCE_GEO=m / f (diagnostics, A/B timing: profiles/r04_geometry_by_columns.log): the 128 x 128 / 64 x 64 geometry
-  // as the operator's own, whatever its rows
-  if (const char* v = std::getenv("SRI_APPLY_FORCE_GEO")) { if (v[0] == 'm') h->geo = GEO_MID; else if (v[0] == 'f') h->geo = GEO_FLAT; }
+  // SRI_DEBUG=force_geo=m / f (A/B timing only: profiles/r04_geometry_by_columns.log): the 128 x 128 / 64 x 64 geometry as the
+  // operator's own, whatever its rows
+  {
+    const std::string v = debug_option("force_geo");
+    if (v == "m") h->geo = GEO_MID; else if (v == "f") h->geo = GEO_FLAT;
+  }
   // The differentiation operators of large grids (and caller-supplied matrices of that size) sum k in the reference's
   // ascending order; the integration operator (||Dn_NN^-1||_inf = 1: no cancellation to protect, and the one the rank-1
   // and fused-step variants are built on) keeps the faster paired order at every size.  The ascending variant exists for
@@ -133,9 +136,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
     delete h;
     return code;
   };
-  // SRI_APPLY_NO_SMALL=1 (diagnostics, A/B timing): keep 64-row operators on the general kernel
-  const char* no_small = std::getenv("SRI_APPLY_NO_SMALL");
-  if (square && small_supported(rows) && !(no_small && no_small[0] == '1')) {
+  // (SRI_OPT_SMALL_KERNEL = 0 keeps a 64-row operator on the general kernel per handle: run())
+  if (square && small_supported(rows)) {
     rc = small_prepare(device);
     if (rc != SRI_OK) return fail(rc);
     std::vector<double> sp;
@@ -157,15 +159,14 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   // part is a launch of the same kernel on the rows it owns (ApplyArgs::rows_out; all k): same k order, same chain of fused
   // multiply-adds per output element — bit-identical to the single-geometry result.  The second launch re-reads the panel
   // (from the Infinity Cache as far as it reaches), which is why thinner last parts do not pay (DESIGN.md §4 "Other grid sizes").
-  // SRI_APPLY_NO_PARTS=1 keeps every operator whole (A/B, tests).
+  // SRI_OPT_ROW_PARTS = 0 launches an operator whole although it is kept in parts (A/B, tests: run()).
   {
-    const char* no_parts = std::getenv("SRI_APPLY_NO_PARTS");
-    const char* no_strip = std::getenv("SRI_APPLY_NO_STRIP");       // A/B: thin last rows as a part of their own instead of a strip
     int np = 0;
-    if (square && !(no_parts && no_parts[0] == '1')) {
+    if (square) {
       plan::RowPart rp[2];
-      const char* no_ext = std::getenv("SRI_APPLY_PARTS_EXT");       // A/B: =0 keeps 256 a + 65 ... 96 / 129 ... 192 rows whole
-      np = plan::row_parts(rows, !(no_strip && no_strip[0] == '1'), rp, !(no_ext && no_ext[0] == '0'));   // (sri_column_plan.h; tests/cpp/column_plan_check.cpp)
+      // A/B only (SRI_DEBUG): strip=0 — thin last rows as a part of their own instead of a strip; parts_ext=0 — 256 a + 65 ... 96 /
+      // 129 ... 192 rows stay whole
+      np = plan::row_parts(rows, debug_option("strip") != "0", rp, debug_option("parts_ext") != "0");   // (sri_column_plan.h; tests/cpp/column_plan_check.cpp)
       for (int i = 0; i < np; ++i) {
         h->parts[i].geo = rp[i].geo;
         h->parts[i].row0 = rp[i].row0;
@@ -228,8 +229,6 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
   // Alternates (sri_column_plan.h): the whole operator once more in each finer geometry — 128 x 128 and 64 x 64 tiles for a
   // 256-row operator, 64 x 64 for a 128-row one (the 64 x 64 geometry has no ascending-k variant: not for operators that use it).
   if (square && rows >= BK && h->geo != GEO_FLAT) {
-    const char* off = std::getenv("SRI_APPLY_COLUMN_PLAN");
-    if (off != nullptr && off[0] == '0') h->column_plan = false;
     const double* wf = (rows % BK != 0) ? w_host : nullptr;
     for (int geo = h->geo - 1; geo >= GEO_FLAT; --geo) {
       if (geo == GEO_FLAT && h->ascending) break;
@@ -292,7 +291,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   int rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
 
-  if (h->d_apack_small != nullptr && !rank1 && quat == nullptr && many == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
+  if (h->d_apack_small != nullptr && h->use_small && !rank1 && quat == nullptr && many == nullptr && small_batch(M, h->num_cus, h->max_workgroups)) {
     h->last_kernel.store("sri_apply_mfma_f64<64x64,dma,one-tile-per-workgroup>", std::memory_order_relaxed);
     return small_launch(h->d_apack_small, dX, ldx, dY, ldy, M, d_tips, h->device, h->num_cus, h->max_workgroups, stream);
   }
@@ -327,7 +326,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.nk = h->nk;
   args.row_blocks = h->row_blocks;
   args.col_tiles = 0;   // set by launch()
-  args.tile_order = 0;  // set by launch()
+  args.tile_order = h->xcd_walk ? 1u : 0u;   // in: the XCD-grouped walk is allowed; launch() decides whether this grid takes it
   args.xs = many ? many->xs : nullptr;
   args.ys = many ? many->ys : nullptr;
   args.panels = many ? static_cast<uint32_t>(many->count) : 0u;
@@ -373,7 +372,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   };
   // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
-  const bool in_parts = h->num_parts != 0 && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
+  const bool in_parts = h->num_parts != 0 && h->use_parts && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
       static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32);
   // the operator's own path over `a.m` columns
   auto primary = [&](const ApplyArgs& cols_args, bool lean) -> int {
@@ -538,6 +537,42 @@ int sri_apply_set_column_plan(sri_apply_t* h, int enable) {
   if (h == nullptr) return SRI_EINVAL;
   h->column_plan = enable != 0;
   return SRI_OK;
+}
+
+int sri_apply_set_option(sri_apply_t* h, int option, long value) {
+  if (h == nullptr) return SRI_EINVAL;
+  switch (option) {
+    case SRI_OPT_COLUMN_PLAN: h->column_plan = value != 0; return SRI_OK;
+    case SRI_OPT_LEAN_TAIL: h->lean_tail = value != 0; return SRI_OK;
+    case SRI_OPT_ROW_PARTS: h->use_parts = value != 0; return SRI_OK;
+    case SRI_OPT_SMALL_KERNEL: h->use_small = value != 0; return SRI_OK;
+    case SRI_OPT_XCD_TILE_WALK: h->xcd_walk = value != 0; return SRI_OK;
+    case SRI_OPT_HOST_COPY_THREADS: return sri_apply_set_host_copy_threads(h, static_cast<int>(value));
+    case SRI_OPT_HOST_BLOCK_COLUMNS:
+      if (value < 0 || (value != 0 && value < 128) || value > (1L << 24)) return SRI_EINVAL;
+      h->host_block_cols = static_cast<size_t>(value) & ~static_cast<size_t>(127);      // whole 128-column tiles
+      return SRI_OK;
+    case SRI_OPT_MAX_WORKGROUPS:
+      if (value < 0 || value > 0x7fffffffL) return SRI_EINVAL;
+      h->max_workgroups = static_cast<uint32_t>(value);
+      return SRI_OK;
+    default: return SRI_EINVAL;
+  }
+}
+
+int sri_apply_get_option(const sri_apply_t* h, int option, long* value) {
+  if (h == nullptr || value == nullptr) return SRI_EINVAL;
+  switch (option) {
+    case SRI_OPT_COLUMN_PLAN: *value = h->column_plan ? 1 : 0; return SRI_OK;
+    case SRI_OPT_LEAN_TAIL: *value = h->lean_tail ? 1 : 0; return SRI_OK;
+    case SRI_OPT_ROW_PARTS: *value = h->use_parts ? 1 : 0; return SRI_OK;
+    case SRI_OPT_SMALL_KERNEL: *value = h->use_small ? 1 : 0; return SRI_OK;
+    case SRI_OPT_XCD_TILE_WALK: *value = h->xcd_walk ? 1 : 0; return SRI_OK;
+    case SRI_OPT_HOST_COPY_THREADS: *value = h->host_copy_threads; return SRI_OK;
+    case SRI_OPT_HOST_BLOCK_COLUMNS: *value = static_cast<long>(h->host_block_cols); return SRI_OK;
+    case SRI_OPT_MAX_WORKGROUPS: *value = static_cast<long>(h->max_workgroups); return SRI_OK;
+    default: return SRI_EINVAL;
+  }
 }
 
 int sri_apply_dim(const sri_apply_t* h, uint32_t* rows) {

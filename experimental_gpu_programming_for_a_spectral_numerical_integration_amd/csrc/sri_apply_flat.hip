@@ -1,90 +1,4 @@
-// sri_apply_flat.hip — every variant of the flat geometry of sri::apply_kernel (GeoFlat): instantiation, residency, dispatch, operator packing
-#include "sri_apply_kernel.h"
-#include "sri_apply_geometries.h"
+// sri_apply_flat.hip — every variant of sri::apply_kernel in the flat geometry (GeoFlat: 64 x 64 tiles, 4 waves, three workgroups per CU: operators of at most 64 rows)
+#include "sri_apply_geometry_impl.h"
 
-namespace sri {
-
-template <class G>
-static int prepare_geometry(int dev) {
-  int rc = prepare<G, true, false, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, false, true>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, true>(dev);
-  if (rc == SRI_OK) rc = prepare<G, false, false, false>(dev);
-  if (rc == SRI_OK) rc = prepare<G, false, true, false>(dev);
-  if constexpr (G::BM >= 128) {                                 // ascending k order: only operators with rows > 512
-    if (rc == SRI_OK) rc = prepare<G, true, false, false, EPI_NONE, 0, true>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true>(dev);
-  }
-  if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
-  if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
-    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_NONE, 0, false, true>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true, true>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2, false, true>(dev);
-  }
-  if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
-    if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 4>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 4>(dev);
-    if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT, 4>(dev);
-  }
-  return rc;
-}
-
-// `lean`: run() has established that the panel's last column may be read up to its last k chunk's end (LEAN twins exist for the
-// 128- and 256-row geometries; the 64-row one is HBM-bound either way).
-template <class G>
-static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials = nullptr, bool lean = false) {
-  const size_t col_tiles = (args.m + G::BN - 1) / G::BN;
-  const int cus = h->num_cus, dev = h->device;
-  const uint32_t cap = h->max_workgroups;
-  const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
-  if constexpr (G::BM >= 128) {
-    if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
-      if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;
-      if (tail && lean) return launch<G, true, false, true, EPI_NONE, 0, true, true>(args, col_tiles, dev, cus, cap, stream);
-      return tail ? launch<G, true, false, true, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream)
-                  : launch<G, true, false, false, EPI_NONE, 0, true>(args, col_tiles, dev, cus, cap, stream);
-    }
-    if (dma && tail && lean) {
-      if (args.qe != nullptr) {
-        if (args.nk >= 3) return launch<G, true, true, true, EPI_QUAT, 2, false, true>(args, col_tiles, dev, cus, cap, stream, partials);
-      } else {
-        return rank1 ? launch<G, true, true, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
-                     : launch<G, true, false, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream);
-      }
-    }
-  }
-  if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
-    if (args.nk >= 3) {
-      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
-      if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
-      return SRI_EUNSUPPORTED;                             // register-staged build: rows < 16, one chunk
-    }
-    if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {
-      if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
-      if (dma) return launch<G, true, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
-      return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
-    }
-    return SRI_EUNSUPPORTED;
-  }
-  if (dma && tail) return rank1 ? launch<G, true, true, true>(args, col_tiles, dev, cus, cap, stream)
-                                : launch<G, true, false, true>(args, col_tiles, dev, cus, cap, stream);
-  if (dma) return rank1 ? launch<G, true, true, false>(args, col_tiles, dev, cus, cap, stream)
-                        : launch<G, true, false, false>(args, col_tiles, dev, cus, cap, stream);
-  return rank1 ? launch<G, false, true, false>(args, col_tiles, dev, cus, cap, stream)
-               : launch<G, false, false, false>(args, col_tiles, dev, cus, cap, stream);
-}
-
-
-int prepare_flat(int dev) { return prepare_geometry<GeoFlat>(dev); }
-int dispatch_flat(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials, bool lean) {
-  return dispatch<GeoFlat>(h, args, dma, rank1, stream, partials, lean);
-}
-void pack_flat(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
-               std::vector<double>& out) {
-  pack_operator<GeoFlat>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
-}
-
-}  // namespace sri
+SRI_DEFINE_GEOMETRY(flat, sri::GeoFlat)

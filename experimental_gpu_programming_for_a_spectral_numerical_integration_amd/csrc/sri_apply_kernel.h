@@ -107,11 +107,22 @@ inline constexpr int k_of(bool asc, int j, int g, int e) { return asc ? k_of_asc
 #ifndef SRI_SCHED_HINTS
 #define SRI_SCHED_HINTS 1            // 0: leave the main-loop instruction order entirely to hipcc (A/B testing)
 #endif
-// A/B knobs of the tile end (tools/ab_apply.py; every combination gives bit-identical results):
+// Diagnostic scaffolding — the STAMP / ABL template parameters of the kernel and the SRI_TAIL_ABL timing ablations — exists only
+// in builds with -DSRI_DIAG (tools/apply_diag.hip, tools/ab_tail.sh): results are WRONG under most of it, and round 4's one GPU
+// fault came from such a build.  The product build never defines SRI_DIAG: the static_assert in the kernel and the #error below
+// keep every diagnostic instantiation out of libsri_hip.so.
+#if defined(SRI_DIAG)
 #ifndef SRI_TAIL_ABL
 #define SRI_TAIL_ABL 0               // timing-only ablations of the odd-row-count variants (tools/ab_tail.sh; results are WRONG when non-zero):
 #endif                               //   1 = no LDS write in tail_fix_fast, 2 = tail stages wait like any other, 4 = plain stores on half-empty waves,
                                      //   8 = every operator takes the TAIL instantiation (with 2: results stay right when rows % 16 == 0)
+#else
+#ifdef SRI_TAIL_ABL
+#error "SRI_TAIL_ABL is diagnostic scaffolding: build with -DSRI_DIAG (never the product library)"
+#endif
+#define SRI_TAIL_ABL 0
+#endif
+// A/B knobs of the tile end (tools/ab_apply.py; every combination gives bit-identical results):
 #ifndef SRI_STORE_SADDR
 #define SRI_STORE_SADDR 1            // 1: full tiles store through `global_store_dwordx4 v_off, v[..], s[base:base+1] offset:imm` —
 #endif                               //    uniform base + constant lane offset + immediate: no vector-ALU address arithmetic, no branches
@@ -210,7 +221,7 @@ struct ApplyArgs {
   const double* const* xs;
   double* const* ys;
   uint32_t panels;
-  uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel), set by launch()
+  uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel); run() says whether it is allowed, launch() decides
   uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
   uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
@@ -406,6 +417,9 @@ enum { EPI_NONE = 0, EPI_QUAT = 1 };
 template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false, bool LEAN = false>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
   constexpr bool ASCK = ASC;
+#if !defined(SRI_DIAG)
+  static_assert(!STAMP && ABL == 0, "stamped / ablated instantiations are diagnostic scaffolding: build with -DSRI_DIAG (tools/apply_diag.hip)");
+#endif
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
   static_assert(EPI == EPI_NONE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
@@ -1826,9 +1840,8 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
   if (max_wgs != 0 && max_wgs < resident) resident = max_wgs;
   const unsigned grid = static_cast<unsigned>(tiles < resident ? tiles : resident);
   // XCD-grouped walk (see the kernel): only where it is well defined — a full grid that splits into 8 XCDs x row blocks,
-  // at least one round of column tiles for everybody — and wanted (SRI_TILE_ORDER=0 keeps the plain walk: A/B, profiles)
-  static const bool order_off = [] { const char* v = std::getenv("SRI_TILE_ORDER"); return v && v[0] == '0'; }();
-  args.tile_order = (!order_off && args.panels == 0 && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
+  // at least one round of column tiles for everybody — and allowed (args.tile_order on entry: SRI_OPT_XCD_TILE_WALK)
+  args.tile_order = (args.tile_order != 0u && args.panels == 0 && args.row_blocks >= 2 && grid % (8u * args.row_blocks) == 0 && col_tiles >= grid / args.row_blocks) ? 1u : 0u;
   if (partials != nullptr) {
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;

@@ -107,6 +107,7 @@ struct CommDeviceGuard {
 struct sri_comm_handle {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  bool force_ragged = false;   // SRI_DEBUG=comm_force_ragged=1 at creation: even shards take the ragged route (lets a one-GPU box test it)
 };
 
 extern "C" {
@@ -142,6 +143,7 @@ int sri_comm_create(sri_comm_t** out, const void* id, int rank, int world, int d
   if (!h) return SRI_ENOMEM;
   h->rank = rank;
   h->world = world;
+  h->force_ragged = sri::debug_option("comm_force_ragged") == "1";
   h->device = device;
   ncclUniqueId u;
   std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
@@ -189,9 +191,7 @@ static int allgather_doubles(sri_comm_t* h, const double* d_local, size_t count_
   if (counts) {
     if (counts[h->rank] != count_local) return SRI_EINVAL;
     for (int i = 0; i < h->world; ++i) equal = equal && counts[i] == count_local;
-    // SRI_COMM_FORCE_RAGGED=1 sends even shards down the ragged route (lets a one- or two-GPU box test it)
-    static const bool force_ragged = [] { const char* v = getenv("SRI_COMM_FORCE_RAGGED"); return v && v[0] == '1'; }();
-    if (force_ragged) equal = false;
+    if (h->force_ragged) equal = false;
   }
   ncclResult_t e;
   if (equal) {

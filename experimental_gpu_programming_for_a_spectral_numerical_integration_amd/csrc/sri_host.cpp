@@ -12,11 +12,26 @@
 #include "sri_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 namespace sri {
+
+// The library's one environment hook (sri_internal.h): the value of `key` in SRI_DEBUG="key=value,key=value".
+std::string debug_option(const char* key) {
+  const char* env = std::getenv("SRI_DEBUG");
+  if (env == nullptr || key == nullptr) return std::string();
+  const size_t klen = std::strlen(key);
+  for (const char* p = env; *p != '\0';) {
+    const char* end = std::strchr(p, ',');
+    const size_t len = end != nullptr ? static_cast<size_t>(end - p) : std::strlen(p);
+    if (len > klen && std::strncmp(p, key, klen) == 0 && p[klen] == '=') return std::string(p + klen + 1, len - klen - 1);
+    p += len + (end != nullptr ? 1 : 0);
+  }
+  return std::string();
+}
 
 // chebyshev_differentiation.h:26
 //   (static_cast<double>(t_L)/2)*(1 + cos(M_PI*static_cast<double>(j++)/static_cast<double>(N-1)))

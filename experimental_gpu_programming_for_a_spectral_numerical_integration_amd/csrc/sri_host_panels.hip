@@ -52,10 +52,6 @@ unsigned default_copy_threads() {
   // Four threads plus the calling one keep both directions of the link fed on the GPU box's host (12.8 ms per 0.54 GB panel
   // against 12.0 ms straight from page-locked memory; 2 threads: 17.2, none: 40.9; more than 4 buy nothing —
   // profiles/r04_host_panel_bench.jsonl), and a node runs one handle per GPU.
-  if (const char* v = std::getenv("SRI_HOST_COPY_THREADS")) {
-    const long n = std::strtol(v, nullptr, 10);
-    if (n >= 0 && n <= 64) return static_cast<unsigned>(n);
-  }
   const unsigned hw = std::thread::hardware_concurrency();
   return hw == 0 ? 4u : std::min(4u, hw);
 }
@@ -274,10 +270,7 @@ int run_host(sri_apply_t* h, const double* X, size_t ldx, const double* x_base, 
   }
   const size_t rows = h->rows;
   size_t cb = host_block_columns(rows, M);
-  if (const char* v = std::getenv("SRI_HOST_BLOCK_COLS")) {      // diagnostics (tools/host_panel_bench.py --block-cols): whole tiles
-    const long n = std::strtol(v, nullptr, 10);
-    if (n >= 128 && n <= (1L << 24)) cb = static_cast<size_t>(n) & ~size_t(127);
-  }
+  if (h->host_block_cols != 0) cb = h->host_block_cols;          // SRI_OPT_HOST_BLOCK_COLUMNS (tools/host_panel_bench.py --block-cols): whole tiles
   if (h->pipe == nullptr) {
     const unsigned threads = h->host_copy_threads >= 0 ? static_cast<unsigned>(h->host_copy_threads) : default_copy_threads();
     h->pipe = new (std::nothrow) HostPipe(threads);

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "sri_capi.h"
@@ -22,6 +23,12 @@ int cheb_interp(uint32_t n_from, uint32_t n_to, double* P, size_t ld);
 // the fine integration operator (and its initial-value weights) as a coarser grid sees it — sri_host.cpp; may throw bad_alloc
 int coarse_view_of_fine_operator(const double* A_f, size_t lda, const double* w_f, uint32_t n_f, uint32_t n_c, std::vector<double>& A_c,
                                  std::vector<double>& w_c);
+
+// ---- the library's ONE environment hook (sri_host.cpp) ------------------------------------------------------------------
+// SRI_DEBUG="key=value,key=value": A/B scaffolding for tools/ and tests/ (force_geo=m|f, strip=0, parts_ext=0, valu_prolong=1,
+// comm_force_ragged=1), read where a handle is CREATED.  Everything a caller may want to switch is a handle option
+// (sri_apply_set_option); nothing else in the library reads the environment.
+std::string debug_option(const char* key);   // "" when SRI_DEBUG is unset or does not name `key`
 
 // ---- error bookkeeping (sri_apply.hip): what sri_last_hip_error() reports -----------------------
 void record_hip_error(int hip_error);
@@ -156,9 +163,13 @@ struct sri_apply_handle {
   };
   Alternate alternates[2];
   int num_alternates = 0;
-  bool column_plan = true;           // sri_apply_set_column_plan; SRI_APPLY_COLUMN_PLAN=0 in the environment at creation: off
+  bool column_plan = true;           // sri_apply_set_column_plan / SRI_OPT_COLUMN_PLAN
   std::string mixed_labels[2][2];    // [primary lean][alternate]: what sri_apply_last_kernel reports for a primary + alternate launch
   bool lean_tail = true;             // odd-row-count operators: take the lean kernels where run() finds them safe (sri_apply_set_lean_tail)
+  bool use_parts = true;             // SRI_OPT_ROW_PARTS: 0 launches the operator whole in its own geometry although it is kept in parts
+  bool use_small = true;             // SRI_OPT_SMALL_KERNEL: 0 keeps 64-row operators on the general kernel
+  bool xcd_walk = true;              // SRI_OPT_XCD_TILE_WALK: 0 keeps the plain tile walk for operators of several row blocks
+  size_t host_block_cols = 0;        // SRI_OPT_HOST_BLOCK_COLUMNS: columns per block of the host-panel pipeline (0 = automatic)
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use
   int host_copy_threads = -1;      // CPU threads that move a host panel into / out of the pinned staging slots; -1 = default

@@ -427,9 +427,8 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
     // Round 4: G^0 = 1/2 A(K) (P [Q_c; q0]) is exactly a fused step — operator P[:, :31] (m x 31), the base node's column
     // P[:, 31] as the rank-1 weights (result = A X - w x_base^T with w = -P[:, 31]), the right-hand side formed in the store
     // stage, the tip row emitted on the way — so the interpolation runs on the MFMA pipe (bound by writing G^0) instead of
-    // one vector-ALU fused multiply-add chain per fine node and rod.  SRI_ROD_VALU_PROLONG=1 keeps the old kernel (A/B).
-    const char* valu = std::getenv("SRI_ROD_VALU_PROLONG");
-    if (!(valu && valu[0] == '1')) {
+    // one vector-ALU fused multiply-add chain per fine node and rod.  SRI_DEBUG=valu_prolong=1 keeps the old kernel (A/B).
+    if (sri::debug_option("valu_prolong") != "1") {
       constexpr uint32_t mc = sri::kCoarseN - 1;
       std::vector<double> Pm(static_cast<size_t>(h->m) * mc), wneg(h->m);
       for (uint32_t i = 0; i < h->m; ++i) {
@@ -450,6 +449,13 @@ int sri_rod_set_predictor(sri_rod_t* h, int enable) {
   if (enable && h->coarse == nullptr && !(h->resident != nullptr && h->m >= 16)) return SRI_EUNSUPPORTED;
   h->use_predictor = enable != 0;
   return SRI_OK;
+}
+
+int sri_rod_set_option(sri_rod_t* h, int option, long value) {
+  if (h == nullptr || h->integ == nullptr) return SRI_EINVAL;
+  const int rc = sri_apply_set_option(h->integ, option, value);
+  if (rc == SRI_OK && h->prolong != nullptr) (void)sri_apply_set_option(h->prolong, option, value);
+  return rc;
 }
 
 int sri_rod_set_resident(sri_rod_t* h, int enable) {

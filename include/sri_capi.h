@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SRI_ABI_VERSION 4
+#define SRI_ABI_VERSION 5
 
 typedef enum sri_status {
     SRI_OK = 0,
@@ -168,7 +168,7 @@ int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double
                        double *Y, size_t ldy, size_t M);
 
 /* CPU threads that copy a host panel into / out of the staging slots (besides the calling thread, which helps):
- * -1 = default (SRI_HOST_COPY_THREADS in the environment, else min(4, hardware threads)), 0 = the calling thread alone. */
+ * -1 = default (min(4, hardware threads)), 0 = the calling thread alone. */
 int sri_apply_set_host_copy_threads(sri_apply_t *h, int threads);
 
 /* pinned != 0: the caller PROMISES that every X, Y and x_base it passes to the _host entry points of this handle is
@@ -182,19 +182,44 @@ int sri_apply_set_host_memory_pinned(sri_apply_t *h, int pinned);
  * the column's end (never used: that part of the on-chip image is overwritten before any arithmetic sees it).  enable != 0
  * (default): where those bytes share their 4-KiB page with the panel's last valid byte — so that reading them cannot fault — the
  * launch takes the kernel variant without the edge handling (1.6 % faster at N = 256); everywhere else, and always with
- * enable == 0, the variant that never reads past the panel.  Same results bit for bit. */
+ * enable == 0, the variant that never reads past the panel.  Same results bit for bit.
+ * THE CONTRACT IN ONE SENTENCE: with ld >= 16 * ceil(rows / 16) the library never reads outside the caller's allocation; with
+ * ld == rows and rows % 16 != 0 it may READ (never write, never use) up to 120 bytes past the panel's last byte, inside the same
+ * 4-KiB page, unless sri_apply_set_lean_tail(h, 0) has been called.  (Memory checkers that track allocations byte-exactly will
+ * flag that read; the edge-safe variants cost 1.6 %.) */
 int sri_apply_set_lean_tail(sri_apply_t *h, int enable);
 
 /* Launch policy of operators of more than 64 rows: which tile geometry takes which columns of a panel.  Every launch walks
  * whole rounds of tiles over the chip, so a panel of 1.1 rounds of 256 x 128 tiles costs 2, and one of a few thousand columns
- * leaves most of the chip idle for a whole tile time.  enable != 0 (default; SRI_APPLY_COLUMN_PLAN=0 in the environment at
- * creation turns it off): per call, the operator's own geometry takes the columns of its full rounds and a finer geometry of the
+ * leaves most of the chip idle for a whole tile time.  enable != 0 (default): per call, the operator's own geometry takes the columns of its full rounds and a finer geometry of the
  * same operator (128 x 128 or 64 x 64 tiles) the rest — or all of a small panel — wherever a cost model built from measured
  * tile times expects at least 5 % to win (csrc/sri_column_plan.h; e.g. N = 256, 4 096 columns: 61.7 -> 13.2 us).  The extra
  * launches go to `stream` one after the other.  enable == 0: always the operator's own geometry.  Same results bit for bit
- * (same k order, same chain of fused multiply-adds per output element).  Plain applies and sri_integrate; the fused step,
- * sri_apply_many and handles with a workgroup cap (sri_apply_set_max_workgroups) keep one geometry. */
+ * (same k order, same chain of fused multiply-adds per output element).  Plain applies and sri_integrate split a panel this
+ * way; the fused step (sri_rod_quaternion_step) takes ONE geometry per launch — its own, or a finer one for ALL columns of a
+ * small batch (the number of partial maxima it writes and the name sri_rod_last_apply_kernel reports change with that choice);
+ * sri_apply_many and handles with a workgroup cap (sri_apply_set_max_workgroups) keep the operator's own geometry. */
 int sri_apply_set_column_plan(sri_apply_t *h, int enable);
+
+/* Every per-handle switch under one entry point (the dedicated setters above remain).  Nothing in the library reads the
+ * environment for these: a process that wants another default calls this after sri_apply_create. */
+typedef enum sri_option {
+    SRI_OPT_COLUMN_PLAN = 1,        /* = sri_apply_set_column_plan (default 1)                                              */
+    SRI_OPT_LEAN_TAIL = 2,          /* = sri_apply_set_lean_tail (default 1)                                                */
+    SRI_OPT_ROW_PARTS = 3,          /* 0: launch the operator whole, in ONE tile geometry, although it is kept in parts
+                                       (rows off the multiples of 64; default 1).  Same bits; A/B timing and tests          */
+    SRI_OPT_SMALL_KERNEL = 4,       /* 0: a 64-row operator never takes the one-tile-per-workgroup kernel (default 1)       */
+    SRI_OPT_XCD_TILE_WALK = 5,      /* 0: operators of several row blocks walk their tiles row block slowest instead of
+                                       grouped by XCD (default 1; same bits, 1.8 x the HBM reads at N = 1024)               */
+    SRI_OPT_HOST_COPY_THREADS = 6,  /* = sri_apply_set_host_copy_threads                                                    */
+    SRI_OPT_HOST_BLOCK_COLUMNS = 7, /* columns per block of the host-panel pipeline, a multiple of 128; 0 = automatic        */
+    SRI_OPT_MAX_WORKGROUPS = 8,     /* = sri_apply_set_max_workgroups                                                       */
+    SRI_OPT_PLAN_CALIBRATION = 9    /* 1 (default): the column plan prices its candidates with tile times THIS device
+                                       produced (a few launches per geometry, once per handle, on the first planned call's
+                                       stream); 0: with the built-in table (csrc/sri_column_plan.h)                         */
+} sri_option;
+int sri_apply_set_option(sri_apply_t *h, int option, long value);
+int sri_apply_get_option(const sri_apply_t *h, int option, long *value);
 
 int sri_apply_destroy(sri_apply_t *h);
 
@@ -222,6 +247,9 @@ int sri_rod_set_resident(sri_rod_t *h, int enable);
  * changes (*iters counts fine-grid iterations).  enable = 0 starts from Q = q_init at every node instead;
  * SRI_EUNSUPPORTED if enabling is impossible (N <= 16: nothing coarser). */
 int sri_rod_set_predictor(sri_rod_t *h, int enable);
+
+/* sri_apply_set_option on every apply handle inside the rod handle (the integration operator, the prolongation). */
+int sri_rod_set_option(sri_rod_t *h, int option, long value);
 
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):
  * d_qe: 9 doubles per rod in main.cpp:187-195 order; dK: m x (3*rods), ldk >= m. */
@@ -307,8 +335,8 @@ const char *sri_rccl_strerror(int rccl_result);
 /* Introspection / diagnostics                                                              */
 /* ---------------------------------------------------------------------------------------- */
 
-/* Name of the kernel variant the last sri_apply()/sri_integrate() on this handle launched
- * (static string, e.g. "sri_apply_mfma_f64<256x64,dma>"). */
+/* Name of the kernel variant(s) the last sri_apply()/sri_integrate() on this handle launched (a string owned by the handle, e.g.
+ * "sri_apply_mfma_f64<256x128,dma>", or "sri_apply_mfma_f64<256x128,dma,lean>|<64x64,dma>" when the column plan split the panel). */
 const char *sri_apply_last_kernel(const sri_apply_t *h);
 
 /* The same for the integration operator inside a rod handle: what its last launch was — a fused quaternion step

@@ -228,10 +228,9 @@ def test_empty_and_error_paths(sri):
 
 
 def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
-    """An operator cut into parts (two launches, two geometries) against the same operator kept whole (SRI_APPLY_NO_PARTS=1 at
-    handle creation): Y, the tip row and sri_integrate's result must be bit-identical — also on a strided panel, where the
+    """An operator cut into parts (two launches, two geometries) against the same operator launched whole (OPT_ROW_PARTS = 0):
+    Y, the tip row and sri_integrate's result must be bit-identical — also on a strided panel, where the
     last part's columns start inside the caller's columns."""
-    import os
     import torch
 
     for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (200, 0, 1000, 1), (209, 1, 515, 0), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
@@ -239,13 +238,11 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
         ops = []
-        for env in ("0", "1"):
-            os.environ["SRI_APPLY_NO_PARTS"] = env
-            try:
-                ops.append(sri.SpectralApply(n, which))
-                ops[-1].set_column_plan(False)
-            finally:
-                del os.environ["SRI_APPLY_NO_PARTS"]
+        for parts in (1, 0):
+            ops.append(sri.SpectralApply(n, which))
+            ops[-1].set_column_plan(False)
+            ops[-1].set_option(sri.OPT_ROW_PARTS, parts)
+            assert ops[-1].get_option(sri.OPT_ROW_PARTS) == parts
         ld = rows + ld_extra
         Xd = torch.full((M, ld), float("nan"), dtype=torch.float64, device="cuda")
         Xd[:, :rows] = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
@@ -619,15 +616,14 @@ def test_randomised_shape_sweep_against_the_oracle_product(sri, oracle):
         assert torch.isnan(Yp[:, rows:]).all()                    # the padding between columns is never written
 
 
-def test_small_batch_kernel_matches_the_general_kernel_bit_for_bit(sri, monkeypatch):
+def test_small_batch_kernel_matches_the_general_kernel_bit_for_bit(sri):
     """64-row operators: batches of at most one tile per resident workgroup take the one-tile kernel (sri_apply_small.hip),
     larger ones the general kernel.  Same arithmetic, same k order: the bits must not depend on which one ran."""
     import torch
 
     op = sri.SpectralApply(64, 0)
-    monkeypatch.setenv("SRI_APPLY_NO_SMALL", "1")
-    general = sri.SpectralApply(64, 0)                      # the switch is read when the handle is created
-    monkeypatch.delenv("SRI_APPLY_NO_SMALL")
+    general = sri.SpectralApply(64, 0)
+    general.set_option(sri.OPT_SMALL_KERNEL, 0)
     g = torch.Generator(device="cuda").manual_seed(3)
     for M in (1, 63, 64, 65, 4097, 16384, 32768, 32769, 100000):
         X = torch.rand((M, 64), dtype=torch.float64, device="cuda", generator=g) * 2 - 1

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(sri):
         assert hasattr(lib, name), f"{name} declared in include/sri_capi.h but not exported"
     # and the Python binding table covers exactly the header
     assert sorted(sri.C_ABI) == names
-    assert sri.load_library().sri_abi_version() == 4
+    assert sri.load_library().sri_abi_version() == 5
 
 
 def test_library_is_gfx950_only(sri):

@@ -49,7 +49,7 @@ print("COMM_OK")
 
 @pytest.mark.parametrize("force_ragged", ["0", "1"])
 def test_one_rank_communicator(force_ragged):
-    env = dict(os.environ, SRI_COMM_FORCE_RAGGED=force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SRI_DEBUG="comm_force_ragged=" + force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", BODY.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "COMM_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 

@@ -56,6 +56,6 @@ def test_multi_gpu_gather_from_cpp(sri, tmp_path, force_ragged):
     per GPU; the box has one, so the communicator has one rank — the same ncclCommInitRank / all-gather calls)."""
     exe = _build(str(tmp_path), os.path.join(ROOT, "examples", "multi_gpu_gather.cpp"), "multi_gpu_gather",
                  extra=("-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"))
-    env = dict(os.environ, SRI_COMM_FORCE_RAGGED=force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SRI_DEBUG="comm_force_ragged=" + force_ragged, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([exe, "1", "1003"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "verified" in r.stdout, (r.stdout, r.stderr[-2000:])

@@ -80,8 +80,8 @@ def test_quaternion_rhs_kernel(sri):
 
 @pytest.mark.parametrize("n,rods", [(16, 5), (17, 40), (10, 3), (33, 70), (64, 333), (65, 100), (129, 50), (200, 77),
                                     (256, 700), (257, 96), (513, 33), (300, 41), (385, 70), (641, 19)])
-@pytest.mark.parametrize("planned", ["0", "1"])     # SRI_APPLY_COLUMN_PLAN: the operator's own tile geometry / a finer one for a small batch
-def test_fused_quaternion_step(sri, oracle, n, rods, planned, monkeypatch):
+@pytest.mark.parametrize("planned", [0, 1])         # OPT_COLUMN_PLAN: the operator's own tile geometry / a finer one for a small batch
+def test_fused_quaternion_step(sri, oracle, n, rods, planned):
     """sri_rod_quaternion_step (the right-hand side formed in the apply's store stage) against
     (a) the unfused composition integrate -> strain -> rhs of the same library: bit-identical, same operation order;
     (b) numpy on the oracle's Dn_NN^-1 / Dn_IN: 1e-12 relative Frobenius.  Covers all three geometries, the
@@ -90,13 +90,13 @@ def test_fused_quaternion_step(sri, oracle, n, rods, planned, monkeypatch):
     batches in the finer geometry the column plan gives a fraction of a round of tiles (one geometry per fused launch)."""
     import torch
 
-    monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", planned)             # read when the handles are created
     m = n - 1
     rng = np.random.default_rng(n * 1000 + rods)
     qe = rng.uniform(-2, 2, size=(rods, 9))
     G = rng.uniform(-1, 1, size=(rods, 4, m))
     q0 = rng.normal(size=(rods, 4))
     rod = sri.RodIntegrator(n)
+    rod.set_option(sri.OPT_COLUMN_PLAN, planned)
     dqe, dG, dq0 = (torch.from_numpy(a).cuda() for a in (qe, G, q0))
     tips = torch.full((rods, 4), float("nan"), dtype=torch.float64, device="cuda")
     tips_prev = torch.from_numpy(rng.normal(size=(rods, 4))).cuda()
@@ -131,12 +131,11 @@ def test_fused_quaternion_step(sri, oracle, n, rods, planned, monkeypatch):
     assert rel <= 1e-12, rel
 
 
-def test_fused_step_lean_and_edge_safe_kernels_agree(sri, monkeypatch):
+def test_fused_step_lean_and_edge_safe_kernels_agree(sri):
     """The fused step of an N = 2^p grid (255, 127, 1023 rows) has the same two variants as the plain odd-row-count apply
     (tests/test_apply_gpu.py::test_lean_and_edge_safe_tail_kernels_agree_and_the_page_rule_decides): same bits."""
     import torch
 
-    monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", "0")                 # (these batches would go to 64 x 64 tiles, which have no lean twin)
     for n, rods in [(256, 1500), (128, 900), (512, 300)]:
         m = n - 1
         g = torch.Generator(device="cuda").manual_seed(n)
@@ -146,8 +145,10 @@ def test_fused_step_lean_and_edge_safe_kernels_agree(sri, monkeypatch):
         off = ((2048 - pool.data_ptr() - 8 * rods * 4 * m) % 4096) // 8          # the panel ends in the middle of a page
         G = pool[off:off + rods * 4 * m].view(rods, 4, m)
         rod = sri.RodIntegrator(n)
+        rod.set_option(sri.OPT_COLUMN_PLAN, 0)                       # (these batches would go to 64 x 64 tiles, which have no lean twin)
         a = rod.quaternion_step(qe, G, q0)
         integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+        integ.set_column_plan(False)
         integ.set_lean_tail(False)
         Q = integ.integrate(G.reshape(rods * 4, m), q0.reshape(-1)).reshape(rods, 4, m)
         ref = rod.quaternion_rhs(rod.strain_field(qe), Q)
@@ -183,7 +184,7 @@ def test_fused_step_on_the_xcd_grouped_tile_walk(sri):
 
 
 @pytest.mark.parametrize("n,rods", [(256, 300), (257, 500), (129, 77), (300, 1000)])
-def test_rod_solve_is_the_same_under_the_column_plan(sri, n, rods, monkeypatch):
+def test_rod_solve_is_the_same_under_the_column_plan(sri, n, rods):
     """A whole solve (predictor, prolongation, fused steps, closing integration, position integration) on a batch that is a
     fraction of a round of tiles: with every launch in the operator's own geometry and with whatever the column plan picks — a
     finer geometry for every fused step and every apply here — Q, R, the iteration count and the last update are identical
@@ -192,9 +193,9 @@ def test_rod_solve_is_the_same_under_the_column_plan(sri, n, rods, monkeypatch):
 
     qe = torch.from_numpy(_qe_batch(rods, seed=n)).cuda()
     out = []
-    for planned in ("0", "1"):
-        monkeypatch.setenv("SRI_APPLY_COLUMN_PLAN", planned)         # read when the handles are created
+    for planned in (0, 1):
         rod = sri.RodIntegrator(n)
+        rod.set_option(sri.OPT_COLUMN_PLAN, planned)
         Q, R = rod.integrate(qe, q_init=[0.6, 0.0, 0.8, 0.0], r_init=[1.0, 2.0, 3.0])
         torch.cuda.synchronize()
         out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update, rod.last_apply_kernel))

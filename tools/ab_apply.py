@@ -2,7 +2,8 @@
 """A/B timing of two builds of libsri_hip.so in ONE process, interleaved rounds (cdna_hip_programming.md §5.4 rule 24).
 
     python tools/ab_apply.py --n 256 --rods 65536 --libs A=path/to/a.so B=path/to/b.so [--rounds 5] [--reps 200]
-    python tools/ab_apply.py --n 64 --rods 4096 --libs small=lib.so general=lib.so,SRI_APPLY_NO_SMALL=1
+    python tools/ab_apply.py --n 64 --rods 4096 --libs small=lib.so general=lib.so,opt:4=0        (sri_option 4 = SRI_OPT_SMALL_KERNEL)
+    python tools/ab_apply.py --n 256 --rods 1024 --libs own=lib.so mid=lib.so,SRI_DEBUG=force_geo=m  (environment at handle creation)
 
 Prints min / median kernel time per variant (HIP events around `reps` back-to-back launches) and the TF/s."""
 import argparse
@@ -39,6 +40,8 @@ def main():
         envs = []
         if "," in path:                                        # name=path,ENV=VAL,...: environment seen by sri_apply_create
             path, *envs = path.split(",")
+        opts = [kv[4:].split("=", 1) for kv in envs if kv.startswith("opt:")]    # opt:<sri_option number>=<value>: set after creation
+        envs = [kv for kv in envs if not kv.startswith("opt:")]
         for kv in envs:
             k, v = kv.split("=", 1)
             os.environ[k] = v
@@ -49,6 +52,9 @@ def main():
         h = vp()
         rc = lib.sri_apply_create(C.byref(h), a.n, a.operator, 0)
         assert rc == 0, rc
+        for k, v in opts:
+            lib.sri_apply_set_option.argtypes = [vp, i32, C.c_long]
+            assert lib.sri_apply_set_option(h, int(k), int(v)) == 0, (k, v)
         for kv in envs:
             os.environ.pop(kv.split("=", 1)[0], None)
         r = u32()

@@ -52,12 +52,11 @@ def main():
     Y = np.empty((rows, M), order="F")
     for threads in [int(t) for t in args.threads.split(",")]:
         for bc in (args.block_cols.split(",") if args.block_cols else [""]):
-            if bc:
-                os.environ["SRI_HOST_BLOCK_COLS"] = bc
             op = sri.SpectralApply(args.n, args.which)
             op.set_host_copy_threads(threads)
+            if bc:
+                op.set_option(sri.OPT_HOST_BLOCK_COLUMNS, int(bc))
             measure(op, X, Y, "staged (pageable caller memory)", {"copy_threads": threads, "block_cols": bc or "library"})
-    os.environ.pop("SRI_HOST_BLOCK_COLS", None)
     if args.pinned:
         import torch
 
