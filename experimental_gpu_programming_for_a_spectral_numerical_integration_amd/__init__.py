@@ -22,7 +22,7 @@ __all__ = [
     "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
     "SpectralApply", "RodIntegrator", "OP_DN", "OP_DNN_INV", "OP_DNN",
     "OPT_COLUMN_PLAN", "OPT_LEAN_TAIL", "OPT_ROW_PARTS", "OPT_SMALL_KERNEL", "OPT_XCD_TILE_WALK", "OPT_HOST_COPY_THREADS",
-    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION",
+    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION", "ROD_OPT_FIRST_SWEEP_CHECK",
 ]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +33,7 @@ OP_DN, OP_DNN_INV, OP_DNN = 0, 1, 2
 # sri_option (include/sri_capi.h)
 (OPT_COLUMN_PLAN, OPT_LEAN_TAIL, OPT_ROW_PARTS, OPT_SMALL_KERNEL, OPT_XCD_TILE_WALK, OPT_HOST_COPY_THREADS, OPT_HOST_BLOCK_COLUMNS,
  OPT_MAX_WORKGROUPS, OPT_PLAN_CALIBRATION) = range(1, 10)
+ROD_OPT_FIRST_SWEEP_CHECK = 100   # sri_rod_set_option only
 
 _dp = C.POINTER(C.c_double)
 _lib: Optional[C.CDLL] = None
@@ -63,6 +64,7 @@ C_ABI = {
     "sri_apply_set_column_plan": (_int, [_vp, _int]),
     "sri_apply_set_host_copy_threads": (_int, [_vp, _int]),
     "sri_apply_set_host_memory_pinned": (_int, [_vp, _int]),
+    "sri_apply_host_trim": (_int, [_vp]),
     "sri_apply_set_option": (_int, [_vp, _int, C.c_long]),
     "sri_apply_get_option": (_int, [_vp, _int, C.POINTER(C.c_long)]),
     "sri_rod_set_option": (_int, [_vp, _int, C.c_long]),
@@ -401,6 +403,10 @@ class SpectralApply:
     def set_host_copy_threads(self, threads: int) -> None:
         """CPU threads that move host panels into / out of the handle's pinned staging slots (-1 = default, 0 = caller only)."""
         _chk(load_library().sri_apply_set_host_copy_threads(self._h, int(threads)), "sri_apply_set_host_copy_threads")
+
+    def host_trim(self) -> None:
+        """Give back the pinned staging ring and device slots of the host-panel path (``sri_apply_host_trim``)."""
+        _chk(load_library().sri_apply_host_trim(self._h), "sri_apply_host_trim")
 
     def set_host_memory_pinned(self, pinned: bool) -> None:
         """Promise that every host panel passed to this handle is page-locked (``hipHostMalloc`` / the caller's own

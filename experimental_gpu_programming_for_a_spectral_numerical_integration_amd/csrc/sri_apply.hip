@@ -269,6 +269,8 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
 
 constexpr int kWhichInterpolation = -3;   // sri_apply_handle::which of create_interpolation_operator()
 
+static int measured_residency(int geo, int dev);
+
 struct ManyPanels {
   const double* const* xs;   // device array of `count` device pointers
   double* const* ys;
@@ -410,37 +412,94 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   plan::Choice choice;
   choice.primary_cols = M;
   if (h->num_alternates != 0 && h->column_plan && dma && many == nullptr && h->max_workgroups == 0) {
+    // (the residency of every geometry is what prepare() measured on THIS device, not the table's figure)
     plan::Launch own[2], finer[2];
     int num_own = 0;
     if (in_parts) {
-      for (int i = 0; i < h->num_parts; ++i) own[num_own++] = plan::Launch{h->parts[i].geo, h->parts[i].row_blocks};
+      for (int i = 0; i < h->num_parts; ++i) own[num_own++] = plan::Launch{h->parts[i].geo, h->parts[i].row_blocks, measured_residency(h->parts[i].geo, h->device)};
     } else {
-      own[num_own++] = plan::Launch{h->geo, h->row_blocks};
+      own[num_own++] = plan::Launch{h->geo, h->row_blocks, measured_residency(h->geo, h->device)};
     }
-    for (int a = 0; a < h->num_alternates; ++a) finer[a] = plan::Launch{h->alternates[a].geo, h->alternates[a].row_blocks};
+    for (int a = 0; a < h->num_alternates; ++a)
+      finer[a] = plan::Launch{h->alternates[a].geo, h->alternates[a].row_blocks, measured_residency(h->alternates[a].geo, h->device)};
     choice = plan::choose(own, num_own, finer, h->num_alternates, M, h->nk, h->num_cus, quat == nullptr);
   }
-  if (choice.alt < 0) {
-    const bool lean = lean_for(0, M);
-    h->last_kernel.store(in_parts ? (lean ? h->parts_name_lean : h->parts_name)
-                                  : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
-    return primary(many == nullptr ? columns(0, M) : args, lean);
+  // the launches of a choice, on `stream`
+  auto execute = [&](const plan::Choice& ch) -> int {
+    if (ch.alt < 0) {
+      const bool lean = lean_for(0, M);
+      h->last_kernel.store(in_parts ? (lean ? h->parts_name_lean : h->parts_name)
+                                    : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
+      return primary(many == nullptr ? columns(0, M) : args, lean);
+    }
+    const sri_apply_handle::Alternate& alt = h->alternates[ch.alt];
+    const size_t kept = ch.primary_cols;
+    if (kept != 0) {
+      const bool lean = lean_for(0, kept);
+      const int prc = primary(columns(0, kept), lean);
+      if (prc != SRI_OK) return prc;
+      h->last_kernel.store(h->mixed_labels[lean ? 1 : 0][ch.alt].c_str(), std::memory_order_relaxed);
+    }
+    ApplyArgs rest = columns(kept, M - kept);
+    rest.apack = alt.d_apack;
+    rest.row_blocks = alt.row_blocks;
+    const bool rest_lean = lean_for(kept, M - kept) && alt.geo != GEO_FLAT;
+    if (kept == 0) h->last_kernel.store(kernel_name(alt.geo, true, quat != nullptr, rest_lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
+    return alt.geo == GEO_MID ? dispatch_mid(h, rest, dma, rank1, stream, partials, rest_lean)
+                              : dispatch_flat(h, rest, dma, rank1, stream, partials, false);
+  };
+  // The cost model ranks candidates with ONE device's tile times (sri_column_plan.h).  Where it wants to deviate from the
+  // operator's own geometry, the first call at this column count lets THIS device decide: both schedules run on the call's own
+  // panel (they write the same bits), own - planned - planned - own between five events, and the handle remembers which one
+  // was faster (a tie within 3 % goes to the own geometry).  Plain applies and sri_integrate only (a fused step must run once);
+  // never inside a stream capture (the model decides there); SRI_OPT_PLAN_CALIBRATION = 0 trusts the model everywhere.
+  if (choice.alt >= 0 && quat == nullptr && h->plan_calibrate) {
+    plan::Choice own_only;
+    own_only.primary_cols = M;
+    sri_apply_handle::PlanVerdict* verdict = nullptr;
+    for (int i = 0; i < h->plan_verdict_count; ++i)
+      if (h->plan_verdicts[i].cols == M && h->plan_verdicts[i].rank1 == rank1) verdict = &h->plan_verdicts[i];
+    if (verdict != nullptr) return execute(verdict->use_plan ? choice : own_only);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
+      (void)hipGetLastError();
+      capturing = hipStreamCaptureStatusActive;                        // (cannot tell: do not synchronise)
+    }
+    if (capturing == hipStreamCaptureStatusNone) {
+      for (hipEvent_t& e : h->plan_events)
+        if (e == nullptr) SRI_HIP(hipEventCreate(&e));
+      const plan::Choice* order[4] = {&own_only, &choice, &choice, &own_only};
+      SRI_HIP(hipEventRecord(h->plan_events[0], stream));
+      for (int i = 0; i < 4; ++i) {
+        rc = execute(*order[i]);
+        if (rc != SRI_OK) return rc;
+        SRI_HIP(hipEventRecord(h->plan_events[i + 1], stream));
+      }
+      SRI_HIP(hipEventSynchronize(h->plan_events[4]));
+      float t[4] = {0, 0, 0, 0};
+      for (int i = 0; i < 4; ++i) SRI_HIP(hipEventElapsedTime(&t[i], h->plan_events[i], h->plan_events[i + 1]));
+      sri_apply_handle::PlanVerdict& v = h->plan_verdicts[h->plan_verdict_next];
+      h->plan_verdict_next = (h->plan_verdict_next + 1) % sri_apply_handle::kPlanVerdicts;
+      if (h->plan_verdict_count < sri_apply_handle::kPlanVerdicts) ++h->plan_verdict_count;
+      v.cols = M;
+      v.rank1 = rank1;
+      v.own_us = 1e3f * std::min(t[0], t[3]);
+      v.plan_us = 1e3f * std::min(t[1], t[2]);
+      v.use_plan = v.plan_us < 0.97f * v.own_us;
+      if (!v.use_plan) h->last_kernel.store(in_parts ? (lean_for(0, M) ? h->parts_name_lean : h->parts_name)
+                                                     : kernel_name(h->geo, dma, false, lean_for(0, M)), std::memory_order_relaxed);
+      // (the last schedule that ran was the own geometry's: Y is complete either way; last_kernel names what later calls will take)
+      if (v.use_plan) {
+        // report the planned schedule's name without running it a third time: the labels execute() would store
+        const size_t kept = choice.primary_cols;
+        const sri_apply_handle::Alternate& alt = h->alternates[choice.alt];
+        if (kept != 0) h->last_kernel.store(h->mixed_labels[lean_for(0, kept) ? 1 : 0][choice.alt].c_str(), std::memory_order_relaxed);
+        else h->last_kernel.store(kernel_name(alt.geo, true, false, lean_for(0, M) && alt.geo != GEO_FLAT), std::memory_order_relaxed);
+      }
+      return SRI_OK;
+    }
   }
-  const sri_apply_handle::Alternate& alt = h->alternates[choice.alt];
-  const size_t kept = choice.primary_cols;
-  if (kept != 0) {
-    const bool lean = lean_for(0, kept);
-    rc = primary(columns(0, kept), lean);
-    if (rc != SRI_OK) return rc;
-    h->last_kernel.store(h->mixed_labels[lean ? 1 : 0][choice.alt].c_str(), std::memory_order_relaxed);
-  }
-  ApplyArgs rest = columns(kept, M - kept);
-  rest.apack = alt.d_apack;
-  rest.row_blocks = alt.row_blocks;
-  const bool rest_lean = lean_for(kept, M - kept) && alt.geo != GEO_FLAT;
-  if (kept == 0) h->last_kernel.store(kernel_name(alt.geo, true, quat != nullptr, rest_lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
-  return alt.geo == GEO_MID ? dispatch_mid(h, rest, dma, rank1, stream, partials, rest_lean)
-                            : dispatch_flat(h, rest, dma, rank1, stream, partials, false);
+  return execute(choice);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,
@@ -460,6 +519,23 @@ int apply_device_panel(sri_apply_t* h, const double* dX, size_t ldx, double* dY,
 int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t kdim, const double* A, size_t lda, const double* w, int device) {
   if (w == nullptr || kdim < 16 || kdim % BK == 0) return SRI_EUNSUPPORTED;      // (the rank-1 term rides in the free slot of the last k chunk)
   return create_from_matrix(out, kdim, A, lda, w, kWhichInterpolation, device, rows_out);
+}
+
+// resident workgroups per CU of geometry `geo` on `dev`, as its prepare() measured them (0: never prepared — the plan's table then)
+static int measured_residency(int geo, int dev) {
+  switch (geo) {
+    case GEO_FLAT: return resident_flat(dev);
+    case GEO_MID: return resident_mid(dev);
+    case GEO_TALL: return resident_tall(dev);
+    case GEO_WIDE: return resident_wide64(dev);
+    case GEO_WIDE32: return resident_wide32(dev);
+    case GEO_TALL_STRIP: return resident_strip(dev);
+    case GEO_96: return resident_g96(dev);
+    case GEO_192: return resident_g192(dev);
+    case GEO_160: return resident_g160(dev);
+    case GEO_224: return resident_g224(dev);
+    default: return 0;
+  }
 }
 
 uint32_t max_partials(const sri_apply_t* h) { return h ? static_cast<uint32_t>(h->num_cus) * 8u * 4u : 0; }
@@ -547,6 +623,10 @@ int sri_apply_set_option(sri_apply_t* h, int option, long value) {
     case SRI_OPT_ROW_PARTS: h->use_parts = value != 0; return SRI_OK;
     case SRI_OPT_SMALL_KERNEL: h->use_small = value != 0; return SRI_OK;
     case SRI_OPT_XCD_TILE_WALK: h->xcd_walk = value != 0; return SRI_OK;
+    case SRI_OPT_PLAN_CALIBRATION:
+      h->plan_calibrate = value != 0;
+      h->plan_verdict_count = h->plan_verdict_next = 0;                 // (what was measured is forgotten either way)
+      return SRI_OK;
     case SRI_OPT_HOST_COPY_THREADS: return sri_apply_set_host_copy_threads(h, static_cast<int>(value));
     case SRI_OPT_HOST_BLOCK_COLUMNS:
       if (value < 0 || (value != 0 && value < 128) || value > (1L << 24)) return SRI_EINVAL;
@@ -568,6 +648,7 @@ int sri_apply_get_option(const sri_apply_t* h, int option, long* value) {
     case SRI_OPT_ROW_PARTS: *value = h->use_parts ? 1 : 0; return SRI_OK;
     case SRI_OPT_SMALL_KERNEL: *value = h->use_small ? 1 : 0; return SRI_OK;
     case SRI_OPT_XCD_TILE_WALK: *value = h->xcd_walk ? 1 : 0; return SRI_OK;
+    case SRI_OPT_PLAN_CALIBRATION: *value = h->plan_calibrate ? 1 : 0; return SRI_OK;
     case SRI_OPT_HOST_COPY_THREADS: *value = h->host_copy_threads; return SRI_OK;
     case SRI_OPT_HOST_BLOCK_COLUMNS: *value = static_cast<long>(h->host_block_cols); return SRI_OK;
     case SRI_OPT_MAX_WORKGROUPS: *value = static_cast<long>(h->max_workgroups); return SRI_OK;
@@ -622,6 +703,8 @@ int sri_apply_destroy(sri_apply_t* h) {
   for (sri_apply_handle::Alternate& alt : h->alternates)
     if (alt.d_apack) (void)hipFree(alt.d_apack);
   sri::host_pipe_destroy(h->pipe);   // sri_host_panels.hip
+  for (hipEvent_t e : h->plan_events)
+    if (e != nullptr) (void)hipEventDestroy(e);
   delete h;
   return SRI_OK;
 }

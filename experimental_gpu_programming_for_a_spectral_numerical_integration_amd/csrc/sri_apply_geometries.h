@@ -12,6 +12,7 @@ struct ApplyArgs;
 
 #define SRI_GEOMETRY_DECL(name)                                                                                                    \
   int prepare_##name(int dev);                                                                                                     \
+  int resident_##name(int dev);   /* workgroups of the plain variant one CU keeps resident, as prepare() measured (0: not prepared) */ \
   int dispatch_##name(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials, bool lean); \
   void pack_##name(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc, \
                    std::vector<double>& out);
@@ -45,6 +46,13 @@ void pack_wide64(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint
 void pack_wide32(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
                  std::vector<double>& out);
 
+int resident_g96(int dev);
+int resident_g192(int dev);
+int resident_g224(int dev);
+int resident_g160(int dev);
+int resident_wide64(int dev);
+int resident_wide32(int dev);
+int resident_strip(int dev);
 int prepare_strip(int dev);
 int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean);
 void pack_strip(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,

@@ -23,15 +23,19 @@ static int prepare_geometry(int dev) {
     if (rc == SRI_OK) rc = prepare<G, true, false, false, EPI_NONE, 0, true>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true>(dev);
   }
-  if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
-  if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
+  if constexpr (G::QUAT_OK) {
+    if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
+  }
   if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_NONE, 0, false, true>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, true, true>(dev);
-    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2, false, true>(dev);
+    if constexpr (G::QUAT_OK) {
+      if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2, false, true>(dev);
+    }
   }
-  if constexpr (G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
+  if constexpr (G::QUAT_OK && G::lds_bytes_quat(4) + G::XB_BYTES <= 160 * 1024) {          // tiles of one or two k chunks only exist for rows <= 32
     if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 4>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 4>(dev);
     if (rc == SRI_OK) rc = prepare<G, false, true, false, EPI_QUAT, 4>(dev);
@@ -56,7 +60,9 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
     }
     if (dma && tail && lean) {
       if (args.qe != nullptr) {
-        if (args.nk >= 3) return launch<G, true, true, true, EPI_QUAT, 2, false, true>(args, col_tiles, dev, cus, cap, stream, partials);
+        if constexpr (G::QUAT_OK) {
+          if (args.nk >= 3) return launch<G, true, true, true, EPI_QUAT, 2, false, true>(args, col_tiles, dev, cus, cap, stream, partials);
+        }
       } else {
         return rank1 ? launch<G, true, true, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
                      : launch<G, true, false, true, EPI_NONE, 0, false, true>(args, col_tiles, dev, cus, cap, stream);
@@ -64,6 +70,9 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
     }
   }
   if (args.qe != nullptr) {                               // fused quaternion iteration (always with the rank-1 term)
+    if constexpr (!G::QUAT_OK) {
+      return SRI_EUNSUPPORTED;                             // (A/B geometries without room for the epilogue's side buffers)
+    } else {
     if (args.nk >= 3) {
       if (dma && tail) return launch<G, true, true, true, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
       if (dma) return launch<G, true, true, false, EPI_QUAT, 2>(args, col_tiles, dev, cus, cap, stream, partials);
@@ -75,6 +84,7 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
       return launch<G, false, true, false, EPI_QUAT, 4>(args, col_tiles, dev, cus, cap, stream, partials);
     }
     return SRI_EUNSUPPORTED;
+    }
   }
   if (dma && tail) return rank1 ? launch<G, true, true, true>(args, col_tiles, dev, cus, cap, stream)
                                 : launch<G, true, false, true>(args, col_tiles, dev, cus, cap, stream);
@@ -90,6 +100,7 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
 #define SRI_DEFINE_GEOMETRY(name, Geometry)                                                                                       \
   namespace sri {                                                                                                                  \
   int prepare_##name(int dev) { return prepare_geometry<Geometry>(dev); }                                                          \
+  int resident_##name(int dev) { return (dev < 0 || dev >= kMaxDevices) ? 0 : residency<Geometry, true, false, false>(dev).load(std::memory_order_acquire); } \
   int dispatch_##name(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1, hipStream_t stream, uint32_t* partials, bool lean) { \
     return dispatch<Geometry>(h, args, dma, rank1, stream, partials, lean);                                                        \
   }                                                                                                                                \

@@ -179,8 +179,9 @@ struct Geo {
   // the fused quaternion epilogue's side buffers: only geometries that satisfy this may be instantiated with EPI_QUAT
   static constexpr bool QUAT_OK = STRIP == 0 && LDS_BYTES + 2 * SIDE_BYTES + XB_BYTES <= 160 * 1024 && P1_BYTES % 512 == 0 && TIPS_BYTES <= 1024 &&
                                   (P1_BYTES + 1023) / 1024 + 1 <= NW;   // P1 slab and previous tips: at most one 1-KiB DMA piece per wave
-  static_assert(A_BYTES % 1024 == 0 && (STRIP != 0 || A_BYTES % (1024 * NW) == 0) && X_BYTES % (1024 * NW) == 0,
-                "stage must split into whole 1-KiB DMA pieces per wave");
+  // (an operator slab that does not split evenly over the waves — the strip's 34 pieces, a 96-row block's 12 over eight waves —
+  // has its last pieces fetched twice: same bytes, same place)
+  static_assert(A_BYTES % 1024 == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
   static_assert(STRIP == 0 || (WM == TN && TM % 2 == 0), "the strip's BN columns are dealt 16 per wave: wave (wm, wn) takes column tile wm of its own 16 TN");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
@@ -982,8 +983,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           const size_t col = col_base4 + tn * 16;
           const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
           double q9[9], xb[4] = {0.0, 0.0, 0.0, 0.0};
+          // K/2 = (q0 + P1 q1 + P2 q2) / 2 with the coefficients halved ONCE per rod: halving is exact and commutes with every
+          // rounding of the sum, so the bits are those of strain_kernel's K times 1/2 — at 9 instead of 3 x 8 multiplies per rod
 #pragma unroll
-          for (int i = 0; i < 9; ++i) q9[i] = qe[i];
+          for (int i = 0; i < 9; ++i) q9[i] = 0.5 * qe[i];
           if constexpr (RANK1_EPI) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xb[r] = q.xb[col + r];
@@ -1013,13 +1016,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                   }
                 }
               }
-              double hk[3];                                      // K/2: halving is exact
+              double hk[3];                                      // K/2 (the coefficients are halved already)
 #pragma unroll
               for (int a = 0; a < 3; ++a) {
                 double sacc = q9[a * 3 + 0];                     // P0 = 1
                 sacc = sacc + P1 * q9[a * 3 + 1];
                 sacc = sacc + P2 * q9[a * 3 + 2];
-                hk[a] = 0.5 * sacc;
+                hk[a] = sacc;
               }
               quat_rhs_half(hk[0], hk[1], hk[2], qw, qx, qy, qz, gq[e]);
             }
@@ -1030,7 +1033,9 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 cb += ldy8;
                 asm volatile("" : "+s"(cb));
               }
-              const d2 v = pack2(gq[0][r], gq[1][r]);
+              // (no pack2 here: the two halves are fresh vector-ALU results, which the register allocator places side by side —
+              // the plain epilogue's come out of accumulator tuples and have to be moved)
+              const d2 v = d2{gq[0][r], gq[1][r]};
               if constexpr (TAIL && t == TM / 2 - 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("s_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, %4\n\t"
@@ -1629,7 +1634,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       seg_mark(0);
       const uint32_t rslot = slot_i;
       if constexpr (REFILL && !PIECES) stage_issue();
-      read_pair(next_slot, 0, pa, pb);                               // (s, 0): landed, consumed 7 groups later
+      // (s, 0): landed, consumed 7 groups later — except in the fused quaternion step, whose epilogue needs every register it can
+      // get: there the pair is read BEHIND the tile end below, in every body (a second definition on the tile-closing path only
+      // made hipcc copy fragment and accumulator registers at the join: 100-200 spilled registers), so that the 32 fragment
+      // registers are dead across the epilogue; the early group's MFMAs cover the read's latency.
+      if constexpr (EPI != EPI_QUAT) read_pair(next_slot, 0, pa, pb);
       mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
       seg_mark(1);
@@ -1638,6 +1647,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // (Issuing the late group's DMA pieces half a stage later, out of phase with the early group's, was
       // measured: no gain.)  The stores follow this body's pieces in program order.
       if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
+      if constexpr (EPI == EPI_QUAT) read_pair(slot_c, 0, pa, pb);
       tl_mark(K4{});
       strip_read(slot_c, 0);                                         // (s, 0): the strip's one fragment set is free again
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});
@@ -1718,7 +1728,13 @@ using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring,
 // flight: 64 KiB) so that 2 WG share a CU and cover each other's waits: 64 < rows <= 128, and larger operators whose last 256-row block would be at most half full (create_from_matrix).  Measured at N = 128, 65 536 rods:
 // 0.138 ms against 0.146 ms for the previous 128 x 64 tile with three slots (+5.7 %).  (At N = 256, two row blocks, it is
 // 4 % behind the tall geometry: 0.531 vs 0.509 ms.)
+#ifndef SRI_GEO_MID_ALT
 using GeoMid = Geo<2, 2, 4, 4, 2>;
+#else
+// A/B variant (round 5, N = 128): BM 128 x BN 256, EIGHT waves (2 x 4 of 64 x 64), three ring slots (144 KiB), 1 WG per CU — the tall
+// geometry's stream (two stages in flight, staggered wave groups) on a 128-row block.  Plain / rank-1 launches only.
+using GeoMid = Geo<2, 4, 4, 4, 3>;
+#endif
 using GeoFlat = Geo<1, 4, 4, 1, 3>;   // BM  64 x BN  64, 4 waves,  48 KiB ring, 3 WG/CU : rows <= 64 (N = 16, 64)
 // BM 64 x BN 256, 4 waves of 64 x 64 side by side (GeoMid's wave tile, MFMA : fragment-read ratio and two-slot ring, 80 KiB,
 // 2 WG per CU): the LAST 1-64 rows of an operator whose row count is not a whole number of 128- / 256-row blocks, as a part
@@ -1739,7 +1755,11 @@ using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
 #ifndef SRI_G96_STAGES
 #define SRI_G96_STAGES 2
 #endif
+#ifndef SRI_GEO_96_ALT
 using Geo96 = Geo<1, 4, 6, 2, SRI_G96_STAGES>;
+#else
+using Geo96 = Geo<1, 8, 6, 2, 3>;      // A/B variant (round 5): BM 96 x BN 256, eight waves side by side, three ring slots (132 KiB), 1 WG per CU
+#endif
 
 // BM 192 x BN 64, 2 x 2 waves of 96 x 32, two-slot ring (64 KiB, 2 WG per CU): operators of 161-192 rows in ONE pass over the panel
 // (before: 128 rows in the 128-row geometry + a second launch for the rest; N = 192: 0.75 -> 0.80 of the peak, 191 rows +15 %)

@@ -17,6 +17,8 @@ int prepare_strip(int dev) {
   return rc;
 }
 
+int resident_strip(int dev) { return (dev < 0 || dev >= kMaxDevices) ? 0 : residency<GeoTallStrip, true, false, false>(dev).load(std::memory_order_acquire); }
+
 int dispatch_strip(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean) {
   using GS = GeoTallStrip;
   const size_t col_tiles = (args.m + GS::BN - 1) / GS::BN;

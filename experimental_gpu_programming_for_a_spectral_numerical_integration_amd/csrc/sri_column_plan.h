@@ -110,19 +110,31 @@ constexpr double kLaunchOverheadUs = 3.5;
 struct Launch {
   int geo = TALL;
   uint32_t row_blocks = 1;
+  int per_cu = 0;            // resident workgroups per CU as MEASURED for this device by prepare() (0: the table's figure)
 };
+
+// microseconds per k chunk of a tile when `sharing` workgroups share the CU (1-based); beyond what the table was measured for —
+// a device that keeps more workgroups resident than the MI355X the table comes from — the last figure grows in proportion
+inline double shared_us(const GeoModel& g, int sharing) {
+  int last = 0;
+  for (int i = 0; i < 5; ++i)
+    if (g.us[i] > 0.0) last = i;
+  if (sharing - 1 <= last) return g.us[sharing < 1 ? 0 : sharing - 1];
+  return g.us[last] * static_cast<double>(sharing) / static_cast<double>(last + 1);
+}
 
 // one persistent launch of `l` over `cols` columns (0 columns: no launch)
 inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
   if (cols == 0) return 0.0;
   const GeoModel& g = model(l.geo);
+  const int per_cu = l.per_cu > 0 ? l.per_cu : g.per_cu;       // (what THIS device keeps resident, when the caller knows)
   const double tiles = std::ceil(static_cast<double>(cols) / g.bn) * l.row_blocks;
-  const double slots = static_cast<double>(cus) * g.per_cu;
+  const double slots = static_cast<double>(cus) * per_cu;
   double t, per_tile = 0.0;
   if (tiles <= slots) {
     // one round: the grid is the tiles and the hardware spreads it over the CUs
-    t = g.us[static_cast<int>(std::ceil(tiles / cus)) - 1];
-  } else if (g.per_cu > 2) {
+    t = shared_us(g, static_cast<int>(std::ceil(tiles / cus)));
+  } else if (per_cu > 2) {
     // many small workgroups per CU: the CU works through its share of the tiles like a queue (measured: 3 072 tiles of 64 x 64
     // take 101 us where 3 rounds of 5 per CU would take 130)
     t = std::ceil(tiles / cus) * g.stream_us;
@@ -133,7 +145,7 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
     const double k_bytes = 16.0 * nk * 8.0;
     const double bytes = tiles * (g.bn * k_bytes + g.bn * 64.0 * 8.0);
     const double panel = static_cast<double>(cols) * k_bytes;
-    const double bytes_per_us = panel <= 128e6 ? 5.2e6 : 4.3e6;
+    const double bytes_per_us = (panel <= 128e6 ? 5.2e6 : 4.3e6) * static_cast<double>(cus) / 256.0;   // (measured on 256 CUs / 8 HBM stacks)
     if (bytes / bytes_per_us > t * nk + per_tile) return bytes / bytes_per_us + kLaunchOverheadUs;
   } else {
     // whole rounds; the tiles behind the last full round go to the FIRST workgroups of a grid that sits per_cu to a CU: up to one
@@ -141,11 +153,11 @@ inline double launch_us(const Launch& l, size_t cols, uint32_t nk, int cus) {
     // "one round + one tile alone" 101; 768 tiles of 64 x 256 behave like the latter) — the mean of both
     const double full = std::floor(tiles / slots);
     const double rem = tiles - full * slots;
-    t = full * g.us[g.per_cu - 1];
+    t = full * shared_us(g, per_cu);
     if (rem > 0.0) {
-      if (g.per_cu == 2 && rem <= cus / 2) t += g.us[0];                               // (a few tiles: each on a CU of its own)
-      else if (g.per_cu == 2 && rem <= cus) t += 0.5 * (g.us[0] + g.us[1]);
-      else t += g.us[g.per_cu - 1];
+      if (per_cu == 2 && rem <= cus / 2) t += g.us[0];                                 // (a few tiles: each on a CU of its own)
+      else if (per_cu == 2 && rem <= cus) t += 0.5 * (g.us[0] + g.us[1]);
+      else t += shared_us(g, per_cu);
     }
   }
   return t * nk + per_tile + kLaunchOverheadUs;
@@ -175,7 +187,7 @@ inline Choice choose(const Launch* primary, int num_primary, const Launch* alter
   if (M == 0 || num_alternates == 0) return best;
   const GeoModel& g0 = model(primary[0].geo);
   // columns of a full round of the first (dominant) primary launch, in whole tiles of the widest primary tile (256)
-  size_t round_cols = static_cast<size_t>(cus) * g0.per_cu / primary[0].row_blocks * g0.bn;
+  size_t round_cols = static_cast<size_t>(cus) * (primary[0].per_cu > 0 ? primary[0].per_cu : g0.per_cu) / primary[0].row_blocks * g0.bn;
   round_cols -= round_cols % 256;
   Choice cand = best;
   for (int a = 0; a < num_alternates; ++a) {

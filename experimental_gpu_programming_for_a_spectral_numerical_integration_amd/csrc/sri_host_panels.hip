@@ -90,23 +90,38 @@ struct HostPipe {
     }
     return SRI_OK;
   }
-  // (re)size one family of SLOTS buffers; nothing is in flight between calls (every call drains before it returns)
+  // (re)size one family of SLOTS buffers; nothing is in flight between calls (every call drains before it returns).  The larger
+  // buffers are allocated FIRST and swapped in only when all of them exist: a failed grow leaves the handle with the (smaller)
+  // buffers it had, so that a later call that fits them still works.  The pipe never shrinks by itself (sri_apply_host_trim).
   template <class Alloc, class Free>
   int grow(char* (&bufs)[SLOTS], size_t& have, size_t want, Alloc alloc, Free release) {
     if (want <= have) return SRI_OK;
+    char* fresh[SLOTS] = {};
     for (int i = 0; i < SLOTS; ++i) {
-      if (bufs[i]) (void)release(bufs[i]);
-      bufs[i] = nullptr;
-    }
-    have = 0;
-    for (int i = 0; i < SLOTS; ++i) {
-      if (alloc(&bufs[i], want) != hipSuccess) {
+      if (alloc(&fresh[i], want) != hipSuccess) {
         (void)hipGetLastError();
+        for (int j = 0; j < i; ++j) (void)release(fresh[j]);
         return SRI_ENOMEM;
       }
     }
+    for (int i = 0; i < SLOTS; ++i) {
+      if (bufs[i]) (void)release(bufs[i]);
+      bufs[i] = fresh[i];
+    }
     have = want;
     return SRI_OK;
+  }
+  // give back the staging ring and the device slots (streams and events stay); the next host call allocates what it needs
+  void trim() {
+    drain();
+    for (int i = 0; i < SLOTS; ++i) {
+      if (dX[i]) (void)hipFree(dX[i]);
+      if (dY[i]) (void)hipFree(dY[i]);
+      if (hIn[i]) (void)hipHostFree(hIn[i]);
+      if (hOut[i]) (void)hipHostFree(hOut[i]);
+      dX[i] = dY[i] = hIn[i] = hOut[i] = nullptr;
+    }
+    dev_in_bytes = dev_out_bytes = host_in_bytes = host_out_bytes = 0;
   }
   int reserve(size_t in_bytes, size_t out_bytes, bool staging) {
     int rc = init();
@@ -213,8 +228,29 @@ bool is_pinned_host(const void* p) {
   }
   return a.type == hipMemoryTypeHost;
 }
+// EVERY byte of [p, p + bytes) page-locked: the allocations (hipHostMalloc) or registrations (hipHostRegister) that the runtime
+// knows are walked from p on — each must be host memory and must start where the previous one ended (the pointer attributes
+// RANGE_START_ADDR / RANGE_SIZE give the allocation or registration an address belongs to).  Checking the two end bytes only (round 4) accepted a range that
+// spans two pinned buffers with a pageable gap between them, and a registration shorter than the range.
 bool is_pinned_host_range(const void* p, size_t bytes) {
-  return bytes == 0 || (is_pinned_host(p) && is_pinned_host(static_cast<const char*>(p) + bytes - 1));
+  const char* at = static_cast<const char*>(p);
+  const char* const end = at + bytes;
+  while (at < end) {
+    if (!is_pinned_host(at)) return false;
+    // (hipMemGetAddressRange reports the size but a NULL base for memory registered with hipHostRegister — measured on ROCm 7.2;
+    //  the pointer attributes give both for registered and for hipHostMalloc memory)
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<char*>(at)) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<char*>(at)) != hipSuccess || base == nullptr || size == 0) {
+      (void)hipGetLastError();
+      return false;
+    }
+    const char* const next = static_cast<const char*>(base) + size;
+    if (next <= at) return false;
+    at = next;
+  }
+  return true;
 }
 
 // The caller declared X, Y and x_base page-locked (hipHostMalloc, or its own hipHostRegister held across the call): the same
@@ -313,6 +349,16 @@ int sri_apply_set_host_copy_threads(sri_apply_t* h, int threads) {
     h->pipe = nullptr;
   }
   h->host_copy_threads = threads;
+  return SRI_OK;
+}
+
+int sri_apply_host_trim(sri_apply_t* h) {
+  if (h == nullptr) return SRI_EINVAL;
+  if (h->pipe != nullptr) {
+    sri::PanelDeviceGuard guard;
+    (void)guard.enter(h->device);
+    h->pipe->trim();
+  }
   return SRI_OK;
 }
 

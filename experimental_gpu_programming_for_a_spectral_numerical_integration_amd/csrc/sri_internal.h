@@ -170,6 +170,18 @@ struct sri_apply_handle {
   bool use_small = true;             // SRI_OPT_SMALL_KERNEL: 0 keeps 64-row operators on the general kernel
   bool xcd_walk = true;              // SRI_OPT_XCD_TILE_WALK: 0 keeps the plain tile walk for operators of several row blocks
   size_t host_block_cols = 0;        // SRI_OPT_HOST_BLOCK_COLUMNS: columns per block of the host-panel pipeline (0 = automatic)
+  // SRI_OPT_PLAN_CALIBRATION: where the column plan's cost model wants columns in a finer geometry, the first call at that
+  // column count times both schedules on the call's own panel (same bits either way) and the handle remembers the winner
+  bool plan_calibrate = true;
+  struct PlanVerdict {
+    size_t cols = 0;
+    bool rank1 = false, use_plan = false;
+    float own_us = 0.0f, plan_us = 0.0f;
+  };
+  static constexpr int kPlanVerdicts = 16;
+  PlanVerdict plan_verdicts[kPlanVerdicts];
+  int plan_verdict_count = 0, plan_verdict_next = 0;
+  hipEvent_t plan_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   std::atomic<const char*> last_kernel{"none"};   // diagnostics only; written by every launch (atomic: no torn read if a second thread asks)
   sri::HostPipe* pipe = nullptr;   // sri_apply_host / sri_integrate_host: streams, events, staging and device slots, built on first use
   int host_copy_threads = -1;      // CPU threads that move a host panel into / out of the pinned staging slots; -1 = default

@@ -24,6 +24,7 @@
 // built with -ffp-contract=off), so K and b are bit-identical to it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -153,56 +154,81 @@ __global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_
   }
 }
 
-// Whole-panel confirmation of the fixed point in one pass: max over (rod, node, component) of |1/2 A(K) Q - G| with K
-// evaluated from qe on the fly (same arithmetic as strain_kernel + quat_rhs_kernel) -> *result as the bits of a
-// non-negative double (NaN -> largest).  Reads 8 doubles per rod and node, writes nothing.
-// Optionally also emits the position right-hand side b = R(q) e1 of every node (B != nullptr; same arithmetic as
-// position_rhs_kernel), since Q is in registers anyway.
-__global__ void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double* __restrict__ nodes, const double* __restrict__ qe,
-                                           const double* __restrict__ Q, size_t ldq, const double* __restrict__ G, size_t ldg,
-                                           unsigned long long* result, double* __restrict__ B, size_t ldb) {
-  double local = 0.0;
-  const size_t total = rods * m;
-  for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
-       t += static_cast<size_t>(gridDim.x) * blockDim.x) {
-    const size_t rod = t / m;
-    const uint32_t i = static_cast<uint32_t>(t % m);
-    const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
-    const double P0 = 1.0, P1 = x;
-    const double P2 = ((2 * 1 + 1) * x * P1 - 1 * P0) / (1 + 1);
+// Whole-panel confirmation of the fixed point in one pass.  With d = 1/2 A(K) Q - G (K evaluated from qe on the fly: same
+// arithmetic as strain_kernel + quat_rhs_kernel), the next update of the iterate is Dn_NN^-1 d, column by column, and two
+// rigorous bounds on its largest entry come out of the same pass:
+//   result[0] = bits of max |d| over the panel              (next update <= ||Dn_NN^-1||_inf * that, and the norm is 1);
+//   result[1] = bits of max over columns of sum_i d_i^2     (next update <= max_i ||row i of Dn_NN^-1||_2 * sqrt(that):
+//               Cauchy-Schwarz — the integration operator averages: its rows have 2-norm ~ 1 / sqrt(N), so rounding-level
+//               noise in d, which the first bound prices at its largest entry, is priced at its root mean square).
+// The caller takes the smaller (NaN -> largest bits in both).  ONE WAVE PER ROD: its lanes walk the nodes, so the four column
+// sums of squares are a wave reduction; the nine strain coefficients are scalar loads.  Reads 8 doubles per rod and node.
+// Optional by-products, since Q is in registers anyway: the position right-hand side b = R(q) e1 of every node (B != nullptr;
+// same arithmetic as position_rhs_kernel) and the next right-hand side 1/2 A(K) Q itself (Gout != nullptr).
+__global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double* __restrict__ nodes, const double* __restrict__ qe,
+                                                                  const double* __restrict__ Q, size_t ldq, const double* __restrict__ G, size_t ldg,
+                                                                  unsigned long long* result, double* __restrict__ B, size_t ldb,
+                                                                  double* __restrict__ Gout, size_t ldo) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t waves = (static_cast<size_t>(gridDim.x) * blockDim.x) >> 6;
+  double dmax = 0.0, ssmax = 0.0;
+  for (size_t rod_v = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; rod_v < rods; rod_v += waves) {
+    // (the rod is the same for the whole wave: say so, and its coefficient loads become scalar)
+    const size_t rod = (static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rod_v >> 32))) << 32) |
+                       static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rod_v)));
     const double* q = qe + rod * 9;
-    double hk[3];
+    double q9[9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      double s = P0 * q[a * 3 + 0];
-      s = s + P1 * q[a * 3 + 1];
-      s = s + P2 * q[a * 3 + 2];
-      hk[a] = 0.5 * s;
-    }
-    const double w = Q[(rod * 4 + 0) * ldq + i], x4 = Q[(rod * 4 + 1) * ldq + i];
-    const double y = Q[(rod * 4 + 2) * ldq + i], z = Q[(rod * 4 + 3) * ldq + i];
-    double gq[4];
-    quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
-    if (B != nullptr) {
-      const double ty = 2 * y, tz = 2 * z;
-      const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
-      B[(rod * 3 + 0) * ldb + i] = 1 - (tyy + tzz);
-      B[(rod * 3 + 1) * ldb + i] = txy + twz;
-      B[(rod * 3 + 2) * ldb + i] = txz - twy;
+    for (int k = 0; k < 9; ++k) q9[k] = q[k];
+    double ss[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (uint32_t i = lane; i < m; i += 64u) {
+      const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+      const double P0 = 1.0, P1 = x;
+      const double P2 = ((2 * 1 + 1) * x * P1 - 1 * P0) / (1 + 1);
+      double hk[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double s = P0 * q9[a * 3 + 0];
+        s = s + P1 * q9[a * 3 + 1];
+        s = s + P2 * q9[a * 3 + 2];
+        hk[a] = 0.5 * s;
+      }
+      const double w = Q[(rod * 4 + 0) * ldq + i], x4 = Q[(rod * 4 + 1) * ldq + i];
+      const double y = Q[(rod * 4 + 2) * ldq + i], z = Q[(rod * 4 + 3) * ldq + i];
+      double gq[4];
+      quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
+      if (B != nullptr) {
+        const double ty = 2 * y, tz = 2 * z;
+        const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
+        B[(rod * 3 + 0) * ldb + i] = 1 - (tyy + tzz);
+        B[(rod * 3 + 1) * ldb + i] = txy + twz;
+        B[(rod * 3 + 2) * ldb + i] = txz - twy;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (Gout != nullptr) Gout[(rod * 4 + a) * ldo + i] = gq[a];
+        const double diff = gq[a] - G[(rod * 4 + a) * ldg + i];
+        const double d = fabs(diff);
+        dmax = d > dmax || d != d ? d : dmax;
+        ss[a] = __builtin_fma(diff, diff, ss[a]);
+      }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const double d = fabs(gq[a] - G[(rod * 4 + a) * ldg + i]);
-      local = d > local || d != d ? d : local;
+      double s = ss[a];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      ssmax = s > ssmax || s != s ? s : ssmax;
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
-    const double other = __shfl_xor(local, off);
-    local = (other > local || other != other) ? other : local;
+    const double other = __shfl_xor(dmax, off);
+    dmax = (other > dmax || other != other) ? other : dmax;
   }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long bits = (local != local) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(local));
-    atomicMax(result, bits);
+  if (lane == 0) {
+    const unsigned long long nan_bits = 0x7ff8000000000000ull;
+    atomicMax(result, (dmax != dmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(dmax)));
+    atomicMax(result + 1, (ssmax != ssmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(ssmax)));
   }
 }
 
@@ -297,6 +323,11 @@ struct sri_rod_handle {
   sri_apply_t* prolong = nullptr;         // the same matrix as an apply handle (m x 31, the base node's column as the rank-1 term): the
                                           // prolongation as ONE fused step on the MFMA pipe; null -> prolong_rhs_kernel (vector ALU)
   bool use_predictor = true;
+  double row_norm2 = 0.0;                 // max_i ||row i of Dn_NN^-1||_2 (as the handle applies it), rounded up; 0 = not known
+  bool first_sweep_check = true;          // after a predicted start: one sweep as a plain product, then the whole-panel bound — before any
+                                          // fused step (SRI_ROD_OPT_FIRST_SWEEP_CHECK)
+  double first_sweep_failed_tol = 0.0;    // the largest tolerance at which that check has failed on this handle: not tried again at or below it
+  double second_sweep_failed_tol = 0.0;   // ... and at which two sweeps (one fused step + the closing product) did not pass either
 };
 
 namespace sri {
@@ -407,6 +438,16 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
     // (with the FINE operator as the coarse nodes see it: coarse_view_of_fine_operator in sri_rod_resident.hip)
     std::vector<double> A_fine(static_cast<size_t>(h->m) * h->m), Din_fine(h->m), w_fine(h->m);
     rc = sri::cheb_integration(n, A_fine.data(), h->m, Din_fine.data());    // (sri_apply_create formed the same matrix; ~0.5 s at N=1024)
+    if (rc == SRI_OK) {
+      // the largest row 2-norm of the operator as applied, for the Cauchy-Schwarz bound of the confirmation pass (rounded up)
+      long double worst = 0.0L;
+      for (uint32_t i = 0; i < h->m; ++i) {
+        long double s2 = 0.0L;
+        for (uint32_t k = 0; k < h->m; ++k) s2 += static_cast<long double>(A_fine[i + static_cast<size_t>(k) * h->m]) * A_fine[i + static_cast<size_t>(k) * h->m];
+        worst = s2 > worst ? s2 : worst;
+      }
+      h->row_norm2 = static_cast<double>(sqrtl(worst)) * (1.0 + 0x1p-40);
+    }
     if (rc == SRI_OK) rc = sri::ivp_weights(integ, w_fine.data());
     if (rc == SRI_OK)
       rc = sri::resident_create(sri::kCoarseN, device, prop.multiProcessorCount, &h->coarse, A_fine.data(), w_fine.data(), n);
@@ -438,6 +479,18 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
       if (sri::create_interpolation_operator(&h->prolong, h->m, mc, Pm.data(), h->m, wneg.data(), device) != SRI_OK) h->prolong = nullptr;
     }
   }
+  if (h->row_norm2 == 0.0) {                                    // small grids on the streaming path (sri_rod_set_resident(h, 0)): same bound
+    std::vector<double> A(static_cast<size_t>(h->m) * h->m), Din(h->m);
+    if (sri::cheb_integration(n, A.data(), h->m, Din.data()) == SRI_OK) {
+      long double worst = 0.0L;
+      for (uint32_t i = 0; i < h->m; ++i) {
+        long double s2 = 0.0L;
+        for (uint32_t k = 0; k < h->m; ++k) s2 += static_cast<long double>(A[i + static_cast<size_t>(k) * h->m]) * A[i + static_cast<size_t>(k) * h->m];
+        worst = s2 > worst ? s2 : worst;
+      }
+      h->row_norm2 = static_cast<double>(sqrtl(worst)) * (1.0 + 0x1p-40);
+    }
+  }
   return SRI_OK;
 }
 
@@ -453,6 +506,11 @@ int sri_rod_set_predictor(sri_rod_t* h, int enable) {
 
 int sri_rod_set_option(sri_rod_t* h, int option, long value) {
   if (h == nullptr || h->integ == nullptr) return SRI_EINVAL;
+  if (option == SRI_ROD_OPT_FIRST_SWEEP_CHECK) {
+    h->first_sweep_check = value != 0;
+    h->first_sweep_failed_tol = h->second_sweep_failed_tol = 0.0;
+    return SRI_OK;
+  }
   const int rc = sri_apply_set_option(h->integ, option, value);
   if (rc == SRI_OK && h->prolong != nullptr) (void)sri_apply_set_option(h->prolong, option, value);
   return rc;
@@ -670,20 +728,68 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   };
   uint32_t it = 0;
   double upd = INFINITY;
+  // The whole-panel criterion for the iterate in dQ, formed from the right-hand side `g`: with d = 1/2 A(K) Q - g the next update
+  // of Q is Dn_NN^-1 d, and upd = min(max |d|, max_i ||row i||_2 * max_col ||d_col||_2) bounds its largest entry (||Dn_NN^-1||_inf
+  // = 1; Cauchy-Schwarz) — both from ONE pass (confirm_fixed_point_kernel), which also leaves the position right-hand side.
+  auto confirm = [&](const double* g) -> int {
+    ROD_HIP(hipMemsetAsync(h->d_diff, 0, 2 * sizeof(unsigned long long), stream));
+    const unsigned blocks = static_cast<unsigned>(std::min<size_t>(2048, (rods + 3) / 4));                 // one wave per rod
+    ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(blocks), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, g, ldw,
+                       h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw, static_cast<double*>(nullptr), ldw));
+    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    ROD_HIP(hipStreamSynchronize(stream));
+    double dinf, ss;
+    std::memcpy(&dinf, h_state, sizeof(double));
+    std::memcpy(&ss, h_state + 1, sizeof(double));
+    if (dinf != dinf || ss != ss) upd = NAN;
+    else upd = (h->row_norm2 > 0.0) ? std::fmin(dinf, h->row_norm2 * std::sqrt(ss) * (1.0 + 0x1p-40)) : dinf;
+    return SRI_OK;
+  };
   // Q from the newest right-hand side; then the bound on the next update over the whole panel -> upd
   auto finish = [&]() -> int {
     cur = bufs[it & 1];
     nxt = bufs[(it + 1) & 1];
     int r = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
     if (r != SRI_OK) return r;
-    ROD_HIP(hipMemsetAsync(h->d_diff, 0, sizeof(unsigned long long), stream));
-    ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(2048), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, cur,
-                       ldw, h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw));
-    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    ROD_HIP(hipStreamSynchronize(stream));
-    std::memcpy(&upd, h_state, sizeof(double));
-    return SRI_OK;
+    return confirm(cur);
   };
+  // After a predicted start the iterate is rounding noise away from the fixed point, and noise is exactly what the integration
+  // operator damps: ONE sweep — as a plain product, Q^1 = Dn_NN^-1 G^0 - w q0^T — and the whole-panel bound on the update of the
+  // NEXT one usually settle it (N = 128 ... 512 at tol = 1e-14: max |d| is 0.4 ... 1.5e-14 there, the Cauchy-Schwarz bound
+  // 1 ... 4e-15, the true next update 2 ... 4e-16 — DESIGN.md §7).  No fused step, no second product.  Where one sweep is known
+  // not to do (the handle remembers the largest tolerance at which the bound failed: N = 1024 at 1e-14), TWO are run outright —
+  // one fused step and the closing product — and the bound is evaluated once, behind them; the tip monitor, which asks for a
+  // quarter of the tolerance at ONE node and so runs four sweeps there, is not consulted.  Only if that fails too does the
+  // device-driven loop below run, from G^0, as if nothing had happened.
+  if (predicted && h->first_sweep_check && tol > h->second_sweep_failed_tol) {
+    if (tol > h->first_sweep_failed_tol) {
+      rc = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
+      if (rc != SRI_OK) return rc;
+      rc = confirm(cur);
+      if (rc != SRI_OK) return rc;
+      if (upd <= tol) {
+        if (iters_out) *iters_out = 1;
+        if (last_update_out) *last_update_out = upd;
+        return SRI_OK;
+      }
+      h->first_sweep_failed_tol = tol;
+    }
+    if (max_iter >= 2) {
+      sri::QuatEpilogue epi{d_qe, h->d_leg};
+      rc = sri::integrate_quat_step(h->integ, cur, ldw, h->d_xb4, epi, nxt, ldw, cols, nullptr, stream);
+      if (rc == SRI_OK) rc = sri_integrate(h->integ, nxt, ldw, h->d_xb4, dQ, ldq, cols, stream);
+      if (rc != SRI_OK) return rc;
+      rc = confirm(nxt);
+      if (rc != SRI_OK) return rc;
+      if (upd <= tol) {
+        if (iters_out) *iters_out = 1;                            // (as the loop counts: fused steps in front of the closing product)
+        if (last_update_out) *last_update_out = upd;
+        return SRI_OK;
+      }
+      h->second_sweep_failed_tol = tol;
+    }
+    upd = INFINITY;
+  }
   while (rc == SRI_OK) {
     // two chunks in flight; the state read back after chunk `slot` tells whether the loop has stopped
     uint32_t slot = 0;

@@ -171,10 +171,17 @@ int sri_integrate_host(sri_apply_t *h, const double *B, size_t ldb, const double
  * -1 = default (min(4, hardware threads)), 0 = the calling thread alone. */
 int sri_apply_set_host_copy_threads(sri_apply_t *h, int threads);
 
+/* Resident footprint of the host-panel path: three pinned staging slots in and three out plus the same on the device, each as
+ * large as the largest block any call of this handle needed (4-32 MiB per slot: up to ~192 MiB pinned + ~192 MiB device), held
+ * until sri_apply_destroy — or until this call, which gives them back (streams and events stay; the next host call allocates
+ * what it needs again).  A failed enlargement keeps the smaller buffers the handle had. */
+int sri_apply_host_trim(sri_apply_t *h);
+
 /* pinned != 0: the caller PROMISES that every X, Y and x_base it passes to the _host entry points of this handle is
  * page-locked host memory (hipHostMalloc, or the caller's own hipHostRegister held across the call).  The copies then go
- * straight from and to the caller's memory — no staging, no CPU copy; the claim is checked (hipPointerGetAttributes on the
- * ends of each range) and a call whose buffers are not page-locked returns SRI_EINVAL.  Default 0. */
+ * straight from and to the caller's memory — no staging, no CPU copy; the claim is checked over the WHOLE of each range (the
+ * allocations / registrations the runtime knows are walked from the first byte to the last) and a call whose buffers are not
+ * page-locked throughout returns SRI_EINVAL.  Default 0. */
 int sri_apply_set_host_memory_pinned(sri_apply_t *h, int pinned);
 
 /* Launch policy of operators whose row count is not a multiple of 16 (every integration operator of an N = 2^p grid).  Their
@@ -248,7 +255,12 @@ int sri_rod_set_resident(sri_rod_t *h, int enable);
  * SRI_EUNSUPPORTED if enabling is impossible (N <= 16: nothing coarser). */
 int sri_rod_set_predictor(sri_rod_t *h, int enable);
 
-/* sri_apply_set_option on every apply handle inside the rod handle (the integration operator, the prolongation). */
+/* sri_apply_set_option on every apply handle inside the rod handle (the integration operator, the prolongation) — or one of
+ * the rod handle's own switches: */
+#define SRI_ROD_OPT_FIRST_SWEEP_CHECK 100 /* 1 (default): after a predicted start, sri_rod_integrate* first runs ONE sweep as a
+                                             plain product and evaluates the whole-panel criterion; only if that fails does the
+                                             fused fixed-point loop run (and the handle does not retry at or below that tol).
+                                             0: always the loop.  Same fixed point, same criterion either way               */
 int sri_rod_set_option(sri_rod_t *h, int option, long value);
 
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):
@@ -277,8 +289,10 @@ int sri_rod_position_rhs(sri_rod_t *h, const double *dQ, size_t ldq, size_t rods
 /* integrateQuaternions (main.cpp:91-118) for a batch: solves (I_4 (x) Dn_NN - 1/2 A(K)) Q = -D_IN q_init by the
  * fixed-point form Q <- Dn_NN^-1 (1/2 A(K) Q - Dn_IN q_init^T) on the MFMA integration apply (one fused launch per
  * iteration, sri_rod_quaternion_step), until the largest update of any entry is <= tol (or max_iter:
- * SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).  dQ: m x (4*rods).  *last_update: a bound on the
- * next update of any entry of Q, max |1/2 A(K) Q - G| over the panel (||Dn_NN^-1||_inf = 1).  The loop is driven
+ * SRI_ENOTCONVERGED).  q_init: 4 HOST doubles (NULL = 1,0,0,0).  dQ: m x (4*rods).  *last_update: a rigorous bound on
+ * the next update of any entry of Q — with d = 1/2 A(K) Q - G over the whole panel, the smaller of max |d| (||Dn_NN^-1||_inf = 1)
+ * and max_i ||row i of Dn_NN^-1||_2 * max_col ||d_col||_2 (Cauchy-Schwarz: the operator averages rounding noise).  *iters: fine
+ * sweeps before the closing product (1 when the first sweep after a predicted start already met the criterion).  The loop is driven
  * on the device (tip-node monitor in the step's epilogue, a control kernel raising a stop word); the host waits on
  * the stream once per chunk of 8 iterations and once at the end, so the stream must not be capturing. */
 int sri_rod_integrate_quaternions(sri_rod_t *h, const double *d_qe, size_t rods, const double *q_init, double *dQ,

@@ -21,6 +21,14 @@ static int failures = 0;
 
 int main() {
   const int cus = 256;
+  // a residency the table has no figure for grows in proportion; the measured one, when given, is what counts
+  CHECK(shared_us(model(TALL), 1) == 3.90 && shared_us(model(TALL), 2) == 7.80, "tall, two to a CU: %.2f", shared_us(model(TALL), 2));
+  CHECK(shared_us(model(FLAT), 5) == 2.90 && shared_us(model(FLAT), 6) > 2.90, "flat, six to a CU: %.2f", shared_us(model(FLAT), 6));
+  {
+    Launch flat3{FLAT, 4, 3}, flat5{FLAT, 4, 0};
+    CHECK(launch_us(flat3, 4096, 16, 256) == launch_us(flat5, 4096, 16, 256), "a single round of one tile per CU does not depend on the residency");
+    CHECK(launch_us(flat3, 49152, 16, 256) > 0.0, "three to a CU");
+  }
   // ---- N = 256 (one 256-row block, 16 chunks): alternates 128 x 128 (2 row blocks) and 64 x 64 (4 row blocks)
   const Launch tall{TALL, 1};
   const Launch finer[2] = {{MID, 2}, {FLAT, 4}};
@@ -72,6 +80,13 @@ int main() {
     if (base == TALL) alt[num_alt++] = Launch{MID, (rows + 127) / 128};
     if (rng() % 4 != 0) alt[num_alt++] = Launch{FLAT, (rows + 63) / 64};
     const size_t M = 1 + rng() % (rng() % 2 ? 5000 : 600000);
+    // other devices: fewer CUs (a partitioned MI355X shows 32 or 64), another residency than the table's (prepare() measures it)
+    static const int cu_counts[4] = {256, 256, 64, 32};
+    const int cus = cu_counts[rng() % 4];
+    if (rng() % 3 == 0) {
+      own[0].per_cu = 1 + static_cast<int>(rng() % 2);
+      for (int a = 0; a < num_alt; ++a) alt[a].per_cu = 1 + static_cast<int>(rng() % 6);
+    }
     const Choice c = choose(own, num_own, alt, num_alt, M, nk, cus);
     CHECK(c.primary_cols <= M, "kept %zu of %zu", c.primary_cols, M);
     CHECK((c.alt < 0) == (c.primary_cols == M), "alt %d kept %zu of %zu", c.alt, c.primary_cols, M);

@@ -438,6 +438,7 @@ def test_apply_is_graph_capturable(sri):
     for n, M, planned, mark in ((256, 4096, False, "<256x128,dma>"), (256, 4096, True, "<64x64,dma>"), (1024, 20000, True, "|")):
         op = sri.SpectralApply(n, 0)
         op.set_column_plan(planned)
+        op.set_option(sri.OPT_PLAN_CALIBRATION, 0)         # (the cost model's choice, whatever this box would measure)
         X = torch.rand((M, n), dtype=torch.float64, device="cuda") * 2 - 1
         Y = torch.zeros_like(X)
         ref = op.apply(X)                                  # eager result
@@ -457,6 +458,46 @@ def test_apply_is_graph_capturable(sri):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(Y, op.apply(X))
+
+
+def test_column_plan_lets_the_device_decide_once_per_column_count(sri):
+    """Round 5: the plan's cost model holds ONE device's tile times, so where it wants columns in a finer geometry the first call
+    at that column count times both schedules on the call's own panel (own - planned - planned - own, same bits) and the handle
+    follows the winner from then on.  Whatever the verdict: the result is the own geometry's, bit for bit, from the very first
+    call; later calls launch one schedule (the reported kernel no longer changes); a call inside a stream capture never
+    measures (it must not synchronise) and still gives those bits; OPT_PLAN_CALIBRATION = 0 takes the model's word."""
+    import torch
+
+    for n, which, M in ((256, 0, 4096), (256, 1, 40000), (512, 0, 40000), (320, 0, 40000), (128, 0, 16384)):
+        ref_op = sri.SpectralApply(n, which)
+        ref_op.set_column_plan(False)
+        rows = ref_op.rows
+        X = torch.rand((M, rows), dtype=torch.float64, device="cuda") * 2 - 1
+        ref = ref_op.apply(X)
+        op = sri.SpectralApply(n, which)
+        assert op.get_option(sri.OPT_PLAN_CALIBRATION) == 1
+        first = op.apply(X)                                 # measures (four executions), ends on a complete Y
+        k1 = op.last_kernel
+        second = op.apply(X)
+        k2 = op.last_kernel
+        third = op.apply(X)
+        torch.cuda.synchronize()
+        assert torch.equal(first, ref) and torch.equal(second, ref) and torch.equal(third, ref), (n, which, M)
+        assert k1 == k2 == op.last_kernel, (k1, k2, op.last_kernel)
+        # a new column count inside a capture: no measurement, the model's choice, the same bits
+        M2 = M - 128
+        Y = torch.zeros((M2, rows), dtype=torch.float64, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                op.apply(X[:M2], out=Y)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Y, ref[:M2])
+        op.set_option(sri.OPT_PLAN_CALIBRATION, 0)
+        assert torch.equal(op.apply(X), ref)
 
 
 def test_apply_host_roundtrip(sri, oracle):

@@ -236,3 +236,66 @@ def test_caller_pinned_memory_is_used_in_place_and_the_claim_is_checked(sri):
         op.integrate_host(X, xb)                                    # plain numpy memory: the promise does not hold
     op.set_host_memory_pinned(False)
     assert np.array_equal(op.integrate_host(X, xb), want)           # back on the staged path
+
+
+def test_a_pinned_claim_is_checked_over_the_whole_range(sri):
+    """Round 5 (advice): the caller's promise of page-locked panels is verified for EVERY byte, not for the two ends — a panel
+    that spans two registered buffers with a pageable gap between them, or a registration shorter than the panel, is refused
+    (SRI_EINVAL) instead of being handed to a copy engine; the same memory registered as a whole is accepted."""
+    import ctypes
+    import torch
+
+    n, M = 64, 6_000
+    op = sri.SpectralApply(n, sri.OP_DN)
+    rows = op.rows
+    X = uniform_panel(rows, M, seed=21)
+    want = op.apply_host(X)
+    Y = np.empty_like(X)
+    rt = torch.cuda.cudart()
+    page = 4096
+    raw = np.empty(X.nbytes + 2 * page, dtype=np.uint8)
+    off = (-raw.ctypes.data) % page
+    buf = raw[off:off + X.nbytes].view(np.float64).reshape(X.shape[::-1]).T        # page-aligned column-major rows x M
+    assert buf.ctypes.data % page == 0 and buf.flags.f_contiguous
+    buf[...] = X
+    Yraw = np.empty(X.nbytes + 2 * page, dtype=np.uint8)
+    yoff = (-Yraw.ctypes.data) % page
+    Yb = Yraw[yoff:yoff + X.nbytes].view(np.float64).reshape(X.shape[::-1]).T
+    ybytes = (X.nbytes + page - 1) // page * page
+    assert int(rt.cudaHostRegister(Yb.ctypes.data, ybytes, 0)) == 0
+    third = (X.nbytes // 3) // page * page
+    op.set_host_memory_pinned(True)
+    try:
+        # two registered thirds with a pageable one between them
+        assert int(rt.cudaHostRegister(buf.ctypes.data, third, 0)) == 0
+        assert int(rt.cudaHostRegister(buf.ctypes.data + 2 * third, ybytes - 2 * third, 0)) == 0
+        with pytest.raises(RuntimeError):
+            op.apply_host(buf, out=Yb)
+        assert int(rt.cudaHostUnregister(buf.ctypes.data + 2 * third)) == 0
+        # a registration shorter than the panel
+        with pytest.raises(RuntimeError):
+            op.apply_host(buf, out=Yb)
+        assert int(rt.cudaHostUnregister(buf.ctypes.data)) == 0
+        # the whole panel registered: accepted, same bits
+        assert int(rt.cudaHostRegister(buf.ctypes.data, ybytes, 0)) == 0
+        out = op.apply_host(buf, out=Yb)
+        assert np.array_equal(out, want)
+        assert int(rt.cudaHostUnregister(buf.ctypes.data)) == 0
+    finally:
+        op.set_host_memory_pinned(False)
+        rt.cudaHostUnregister(Yb.ctypes.data)
+    del ctypes
+
+
+def test_host_staging_can_be_given_back(sri):
+    """sri_apply_host_trim releases the pinned staging ring and the device slots a handle grew for a large panel (round 5
+    advice: the pipe never shrinks by itself); the next host call allocates what it needs and gives the same bits."""
+    op = sri.SpectralApply(128, sri.OP_DN)
+    X = uniform_panel(op.rows, 30_000, seed=4)
+    a = op.apply_host(X)
+    op.host_trim()
+    op.host_trim()                                                   # idempotent
+    small = np.asfortranarray(X[:, :500])
+    assert np.array_equal(op.apply_host(small), a[:, :500])
+    assert np.array_equal(op.apply_host(X), a)
+

@@ -19,7 +19,7 @@ SCR, OCC = r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
 out = ["# Register / spill / occupancy report of every shipped variant of sri::apply_kernel (csrc/sri_apply.hip).",
        "# `make -C <pkg>/csrc asm` (hipcc -Rpass-analysis=kernel-resource-usage, --offload-arch=gfx950) + tools/resource_usage.py.",
        "# lane/VALU: v_readlane + v_writelane (scalar-register spill traffic) and all other vector-ALU instructions in the basic",
-       "# blocks of the ISA that hold at least one v_mfma (stage bodies AND tile ends; the steady stage bodies are the blocks with",
+       "# blocks (label to branch) of the ISA that hold at least one v_mfma (stage bodies AND tile ends; the steady stage bodies are the blocks with",
        "# 28-64 MFMAs and no global_store).  EPI 1 = fused quaternion step, ASC = ascending k order, LEAN = the twin of a TAIL variant",
        "# without the edge handling of the panel's last column (launched where run() finds the bytes past the panel readable).",
        f"{'geometry':28s} DMA R1 TAIL EPI ASC LEAN | VGPR SGPR Sspill Vspill scratch occ | lane / VALU in MFMA blocks | lane ops in store-free MFMA blocks"]
@@ -44,6 +44,8 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
             if not any(x.startswith("global_store") for x in cur):
                 steady_lane += l
 
+    # basic blocks in the strict sense: a label starts one, a branch ends one (round 5: instructions behind a conditional branch
+    # that skips them in every stage but a tile's first — issue_qe, issue_setup — used to be counted with the MFMAs in front of it)
     for ln in body.split("\n"):
         if re.match(r"^\.LBB\d+_\d+:", ln):
             flush(cur)
@@ -52,6 +54,9 @@ for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
             t = ln.strip()
             if t and not t.startswith((";", ".")):
                 cur.append(t)
+                if t.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+                    flush(cur)
+                    cur = []
     flush(cur)
     out.append(f"{GEO.get(','.join(mg.groups()), ','.join(mg.groups())):28s} {m.group(6):>3s} {m.group(7):>2s} {m.group(8):>4s} {m.group(11):>3s} {m.group(12):>3s} {m.group(13):>4s} | "
                f"{g('VGPRs'):>4s} {g('TotalSGPRs'):>4s} {g('SGPRs Spill'):>6s} {g('VGPRs Spill'):>6s} {g(SCR):>7s} {g(OCC):>3s} | "
