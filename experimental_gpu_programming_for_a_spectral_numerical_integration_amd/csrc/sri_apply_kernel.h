@@ -1638,7 +1638,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // get: there the pair is read BEHIND the tile end below, in every body (a second definition on the tile-closing path only
       // made hipcc copy fragment and accumulator registers at the join: 100-200 spilled registers), so that the 32 fragment
       // registers are dead across the epilogue; the early group's MFMAs cover the read's latency.
-      if constexpr (EPI != EPI_QUAT) read_pair(next_slot, 0, pa, pb);
+#ifndef SRI_QUAT_EARLY_READ
+#define SRI_QUAT_EARLY_READ 0        // A/B knob (profiles/r05_ab_fused_step_read_placement.log): 1 = round 4's placement in the fused step too
+#endif
+      constexpr bool LATE_READ = EPI == EPI_QUAT && SRI_QUAT_EARLY_READ == 0;
+      if constexpr (!LATE_READ) read_pair(next_slot, 0, pa, pb);
       mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});
       seg_mark(1);
@@ -1647,7 +1651,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       // (Issuing the late group's DMA pieces half a stage later, out of phase with the early group's, was
       // measured: no gain.)  The stores follow this body's pieces in program order.
       if (advance_compute()) { finish_tile(done_tile, 0u); seg_mark(4); }   // now slot_c names stage s
-      if constexpr (EPI == EPI_QUAT) read_pair(slot_c, 0, pa, pb);
+      if constexpr (LATE_READ) read_pair(slot_c, 0, pa, pb);
       tl_mark(K4{});
       strip_read(slot_c, 0);                                         // (s, 0): the strip's one fragment set is free again
       mfma_groups(pa, pb, I0{}, IL{}, piece, PT{});

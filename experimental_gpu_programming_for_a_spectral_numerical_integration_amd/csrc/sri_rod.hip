@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, si
 #pragma unroll
     for (int k = 0; k < 9; ++k) q9[k] = q[k];
     double ss[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+#ifndef SRI_CONFIRM_NT
+#define SRI_CONFIRM_NT 0             // A/B knob: read-once / write-once accesses of the pass as non-temporal (measured: 1.814-1.835 ms against 1.813-1.827 plain at N = 256 — nothing)
+#endif
+#pragma unroll 4
     for (uint32_t i = lane; i < m; i += 64u) {
       const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
       const double P0 = 1.0, P1 = x;
@@ -194,21 +197,23 @@ __global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, si
         s = s + P2 * q9[a * 3 + 2];
         hk[a] = 0.5 * s;
       }
-      const double w = Q[(rod * 4 + 0) * ldq + i], x4 = Q[(rod * 4 + 1) * ldq + i];
-      const double y = Q[(rod * 4 + 2) * ldq + i], z = Q[(rod * 4 + 3) * ldq + i];
+      auto ld1 = [](const double* p) __attribute__((always_inline)) { return SRI_CONFIRM_NT ? __builtin_nontemporal_load(p) : *p; };
+      auto st1 = [](double* p, double v) __attribute__((always_inline)) { if (SRI_CONFIRM_NT) __builtin_nontemporal_store(v, p); else *p = v; };
+      const double w = ld1(&Q[(rod * 4 + 0) * ldq + i]), x4 = ld1(&Q[(rod * 4 + 1) * ldq + i]);
+      const double y = ld1(&Q[(rod * 4 + 2) * ldq + i]), z = ld1(&Q[(rod * 4 + 3) * ldq + i]);
       double gq[4];
       quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
       if (B != nullptr) {
         const double ty = 2 * y, tz = 2 * z;
         const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
-        B[(rod * 3 + 0) * ldb + i] = 1 - (tyy + tzz);
-        B[(rod * 3 + 1) * ldb + i] = txy + twz;
-        B[(rod * 3 + 2) * ldb + i] = txz - twy;
+        st1(&B[(rod * 3 + 0) * ldb + i], 1 - (tyy + tzz));
+        st1(&B[(rod * 3 + 1) * ldb + i], txy + twz);
+        st1(&B[(rod * 3 + 2) * ldb + i], txz - twy);
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (Gout != nullptr) Gout[(rod * 4 + a) * ldo + i] = gq[a];
-        const double diff = gq[a] - G[(rod * 4 + a) * ldg + i];
+        const double diff = gq[a] - ld1(&G[(rod * 4 + a) * ldg + i]);
         const double d = fabs(diff);
         dmax = d > dmax || d != d ? d : dmax;
         ss[a] = __builtin_fma(diff, diff, ss[a]);
@@ -328,6 +333,13 @@ struct sri_rod_handle {
                                           // fused step (SRI_ROD_OPT_FIRST_SWEEP_CHECK)
   double first_sweep_failed_tol = 0.0;    // the largest tolerance at which that check has failed on this handle: not tried again at or below it
   double second_sweep_failed_tol = 0.0;   // ... and at which two sweeps (one fused step + the closing product) did not pass either
+  // sri_rod_integrate only: where to put the positions.  The sweeps that usually settle a solve enqueue the position product BEHIND
+  // their confirmation pass and in FRONT of the one host wait that reads the bound back (the product only needs the right-hand
+  // side the pass leaves): the wait then overlaps the product instead of preceding it.  positions_done says whether that happened.
+  double* pos_dR = nullptr;
+  size_t pos_ldr = 0;
+  double pos_r0[3] = {0.0, 0.0, 0.0};
+  bool positions_done = false;
 };
 
 namespace sri {
@@ -731,12 +743,23 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // The whole-panel criterion for the iterate in dQ, formed from the right-hand side `g`: with d = 1/2 A(K) Q - g the next update
   // of Q is Dn_NN^-1 d, and upd = min(max |d|, max_i ||row i||_2 * max_col ||d_col||_2) bounds its largest entry (||Dn_NN^-1||_inf
   // = 1; Cauchy-Schwarz) — both from ONE pass (confirm_fixed_point_kernel), which also leaves the position right-hand side.
-  auto confirm = [&](const double* g) -> int {
+  auto confirm = [&](const double* g, bool positions_behind = false) -> int {
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, 2 * sizeof(unsigned long long), stream));
     const unsigned blocks = static_cast<unsigned>(std::min<size_t>(2048, (rods + 3) / 4));                 // one wave per rod
     ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(blocks), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, g, ldw,
                        h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw, static_cast<double*>(nullptr), ldw));
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    h->positions_done = false;
+    if (positions_behind && h->emit_position_rhs && h->pos_dR != nullptr) {
+      // (sri_rod_integrate: the position product in front of the wait; if the bound then fails, the positions are formed again
+      // from the final iterate)
+      const size_t pcols = 3 * rods;
+      ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(pcols, 256)), dim3(256), 0, stream, 1u, pcols, 3u, h->pos_r0[0],
+                         h->pos_r0[1], h->pos_r0[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
+      const int pr = sri_integrate(h->integ, h->d_B, ldw, h->d_xb3, h->pos_dR, h->pos_ldr, pcols, stream);       // main.cpp:172
+      if (pr != SRI_OK) return pr;
+      h->positions_done = true;
+    }
     ROD_HIP(hipStreamSynchronize(stream));
     double dinf, ss;
     std::memcpy(&dinf, h_state, sizeof(double));
@@ -765,13 +788,14 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     if (tol > h->first_sweep_failed_tol) {
       rc = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
       if (rc != SRI_OK) return rc;
-      rc = confirm(cur);
+      rc = confirm(cur, true);
       if (rc != SRI_OK) return rc;
       if (upd <= tol) {
         if (iters_out) *iters_out = 1;
         if (last_update_out) *last_update_out = upd;
         return SRI_OK;
       }
+      h->positions_done = false;
       h->first_sweep_failed_tol = tol;
     }
     if (max_iter >= 2) {
@@ -779,13 +803,14 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       rc = sri::integrate_quat_step(h->integ, cur, ldw, h->d_xb4, epi, nxt, ldw, cols, nullptr, stream);
       if (rc == SRI_OK) rc = sri_integrate(h->integ, nxt, ldw, h->d_xb4, dQ, ldq, cols, stream);
       if (rc != SRI_OK) return rc;
-      rc = confirm(nxt);
+      rc = confirm(nxt, true);
       if (rc != SRI_OK) return rc;
       if (upd <= tol) {
         if (iters_out) *iters_out = 1;                            // (as the loop counts: fused steps in front of the closing product)
         if (last_update_out) *last_update_out = upd;
         return SRI_OK;
       }
+      h->positions_done = false;
       h->second_sweep_failed_tol = tol;
     }
     upd = INFINITY;
@@ -860,15 +885,20 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
   if (h == nullptr || (rods > 0 && dR == nullptr) || ldr < h->m) return SRI_EINVAL;
   // streaming path: the confirmation pass of the quaternion loop has Q in registers and leaves b = R(q) e1 in the
   // workspace, so the position step is just the hot product
+  const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
+  const double* ri = r_init ? r_init : r0;
   h->emit_position_rhs = true;
+  h->pos_dR = dR;
+  h->pos_ldr = ldr;
+  for (int a = 0; a < 3; ++a) h->pos_r0[a] = ri[a];
+  h->positions_done = false;
   int rc = sri_rod_integrate_quaternions(h, d_qe, rods, q_init, dQ, ldq, tol, max_iter, iters_out, last_update_out, stream);
   h->emit_position_rhs = false;
-  if (rc != SRI_OK || rods == 0) return rc;
+  h->pos_dR = nullptr;
+  if (rc != SRI_OK || rods == 0 || h->positions_done) return rc;
   sri::RodDeviceGuard guard;
   rc = guard.enter(h->device);
   if (rc != SRI_OK) return rc;
-  const double r0[3] = {0, 0, 0};                            // main.cpp:151-154
-  const double* ri = r_init ? r_init : r0;
   const size_t cols = 3 * rods;
   ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
                      cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));

@@ -344,8 +344,10 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        # (the expected kernels are what the cost model picks today; where its candidates are close the own geometry may stay)
-        assert (any(mark in outs[1][2] for mark in marks) or outs[1][2] == outs[0][2]) and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
+        # (the expected kernels are what the cost model picked in round 4; since round 5 the model sees the residency this device
+        # measured and the first planned call lets the device decide: any finer geometry for the rest — or none — is accepted)
+        assert (any(mark in outs[1][2] for mark in marks) or outs[1][2] == outs[0][2] or outs[1][2].endswith(("|<64x64,dma>", "|<128x128,dma>"))
+                or outs[1][2] in ("sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<128x128,dma>")) and "|" not in outs[0][2], (n, which, M, outs[0][2], outs[1][2])
         mixed += "|" in outs[1][2]
         finer += outs[1][2] != outs[0][2]
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which, M, outs[1][2])
