@@ -22,7 +22,7 @@ __all__ = [
     "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
     "SpectralApply", "RodIntegrator", "OP_DN", "OP_DNN_INV", "OP_DNN",
     "OPT_COLUMN_PLAN", "OPT_LEAN_TAIL", "OPT_ROW_PARTS", "OPT_SMALL_KERNEL", "OPT_XCD_TILE_WALK", "OPT_HOST_COPY_THREADS",
-    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION", "ROD_OPT_FIRST_SWEEP_CHECK",
+    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION", "ROD_OPT_FIRST_SWEEP_CHECK", "ROD_OPT_FUSED_POSITION_RHS",
 ]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +33,7 @@ OP_DN, OP_DNN_INV, OP_DNN = 0, 1, 2
 # sri_option (include/sri_capi.h)
 (OPT_COLUMN_PLAN, OPT_LEAN_TAIL, OPT_ROW_PARTS, OPT_SMALL_KERNEL, OPT_XCD_TILE_WALK, OPT_HOST_COPY_THREADS, OPT_HOST_BLOCK_COLUMNS,
  OPT_MAX_WORKGROUPS, OPT_PLAN_CALIBRATION) = range(1, 10)
-ROD_OPT_FIRST_SWEEP_CHECK = 100   # sri_rod_set_option only
+ROD_OPT_FIRST_SWEEP_CHECK, ROD_OPT_FUSED_POSITION_RHS = 100, 101   # sri_rod_set_option only
 
 _dp = C.POINTER(C.c_double)
 _lib: Optional[C.CDLL] = None

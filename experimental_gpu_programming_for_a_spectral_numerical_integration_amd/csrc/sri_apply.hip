@@ -18,7 +18,10 @@ static_assert(plan::FLAT == GEO_FLAT && plan::MID == GEO_MID && plan::TALL == GE
 static thread_local int g_last_hip_error = 0;
 void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 
-static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean = false) {
+static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean = false, bool qb = false) {
+  // (the closing product of a rod solve, EPI_QB: Q and the position right-hand side from one launch — 128- and 256-row geometries)
+  static const char* qb_names[2] = {"sri_apply_mfma_f64<256x128,dma,q+b>", "sri_apply_mfma_f64<256x128,dma,q+b,lean>"};
+  if (qb && geo == GEO_TALL) return qb_names[lean ? 1 : 0];
   static const char* names[3][4] = {
       {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<64x64,reg,quat>",
        "sri_apply_mfma_f64<64x64,dma,quat>"},
@@ -277,10 +280,24 @@ struct ManyPanels {
   size_t count;
 };
 
+struct PositionOut {         // integrate_with_position_rhs: the second panel of an EPI_QB launch
+  double* b;
+  size_t ld;
+};
+
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
                hipStream_t stream, double* d_tips = nullptr, const QuatEpilogue* quat = nullptr, uint32_t* partials = nullptr,
-               const ManyPanels* many = nullptr) {
+               const ManyPanels* many = nullptr, const PositionOut* pos = nullptr) {
   if (h == nullptr || ldx < h->rows || ldy < h->rows_out) return SRI_EINVAL;
+  if (pos != nullptr) {
+    if (pos->b == nullptr || quat != nullptr || many != nullptr || d_tips != nullptr || d_xb == nullptr || M % 4 != 0 ||
+        pos->ld < h->rows_out + (h->rows_out & 1u))
+      return SRI_EINVAL;
+    // (the variant exists for odd-row-count operators in the 256-row geometry, paired k order, LDS-DMA path: in 128 x 128 tiles —
+    //  N = 128, and 257 ... 384 rows — three more stores per rod and row pair at every tile end cost what the lighter pass saves:
+    //  profiles/r05_rod_ab_closing_product.log)
+    if (h->rows % 16 == 0 || h->rows < 16 || h->geo != GEO_TALL || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
+  }
   if (many == nullptr && M > 0 && (dX == nullptr || dY == nullptr)) return SRI_EINVAL;
   if (many != nullptr && (many->xs == nullptr || many->ys == nullptr || d_xb != nullptr || d_tips != nullptr || quat != nullptr)) return SRI_EINVAL;
   if (M == 0 || (many != nullptr && many->count == 0)) return SRI_OK;
@@ -333,6 +350,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.ys = many ? many->ys : nullptr;
   args.panels = many ? static_cast<uint32_t>(many->count) : 0u;
   args.stamps = nullptr;
+  args.y2 = pos ? pos->b : nullptr;
+  args.ldy2 = pos ? pos->ld : 0;
 
   // LDS-DMA (16 bytes per lane) and 16-byte stores work at 8-byte alignment on gfx950 at ~96 % of the aligned
   // rate (tools/unaligned_probe.hip), so any fp64 panel takes the DMA path; a row count that is not a multiple
@@ -365,6 +384,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     if (many == nullptr) {
       a.x = dX + col0 * ldx;
       a.y = dY + col0 * ldy;
+      if (pos != nullptr) a.y2 = pos->b + col0 / 4 * 3 * pos->ld;
       a.nt_stores = (ldy % 16 == 0 && reinterpret_cast<uintptr_t>(a.y) % 128 == 0) ? 1u : 0u;
     }
     if (d_xb != nullptr) a.xb = d_xb + col0;
@@ -374,7 +394,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   };
   // Parts: plain and rank-1-EPILOGUE launches only (the rank-1 term folded into the product needs the x_base side buffer, which
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
-  const bool in_parts = h->num_parts != 0 && h->use_parts && dma && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
+  const bool in_parts = h->num_parts != 0 && h->use_parts && dma && pos == nullptr && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
       static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32);
   // the operator's own path over `a.m` columns
   auto primary = [&](const ApplyArgs& cols_args, bool lean) -> int {
@@ -411,7 +431,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // (its convergence monitors belong to the workgroups of one grid) — its own, or a finer one for all columns of a small batch.
   plan::Choice choice;
   choice.primary_cols = M;
-  if (h->num_alternates != 0 && h->column_plan && dma && many == nullptr && h->max_workgroups == 0) {
+  if (h->num_alternates != 0 && h->column_plan && dma && many == nullptr && h->max_workgroups == 0 && pos == nullptr) {
     // (the residency of every geometry is what prepare() measured on THIS device, not the table's figure)
     plan::Launch own[2], finer[2];
     int num_own = 0;
@@ -429,7 +449,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     if (ch.alt < 0) {
       const bool lean = lean_for(0, M);
       h->last_kernel.store(in_parts ? (lean ? h->parts_name_lean : h->parts_name)
-                                    : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3)), std::memory_order_relaxed);
+                                    : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3), pos != nullptr), std::memory_order_relaxed);
       return primary(many == nullptr ? columns(0, M) : args, lean);
     }
     const sri_apply_handle::Alternate& alt = h->alternates[ch.alt];
@@ -500,6 +520,13 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     }
   }
   return execute(choice);
+}
+
+int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, double* dQ, size_t ldq, double* dB,
+                                size_t ldb, size_t M, void* stream) {
+  if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
+  const PositionOut pos{dB, ldb};
+  return run(h, dG, ldg, dQ, ldq, M, d_x_base, static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, nullptr, &pos);
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,

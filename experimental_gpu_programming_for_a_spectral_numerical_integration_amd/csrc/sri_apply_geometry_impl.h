@@ -27,6 +27,10 @@ static int prepare_geometry(int dev) {
     if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QUAT, 2>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QUAT, 2>(dev);
   }
+  if constexpr (G::BM >= 256 && G::STRIP == 0) {                // the closing product of a rod solve: Q and the position right-hand side
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QB, 0>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QB, 0, false, true>(dev);
+  }
   if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_NONE, 0, false, true>(dev);
@@ -51,6 +55,15 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
+  if (args.y2 != nullptr) {                                       // EPI_QB (run() has checked that the handle is of that kind)
+    if constexpr (G::BM >= 256 && G::STRIP == 0) {
+      if (!dma || !tail || !rank1 || h->ascending || args.qe != nullptr) return SRI_EUNSUPPORTED;
+      return lean ? launch<G, true, true, true, EPI_QB, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
+                  : launch<G, true, true, true, EPI_QB, 0>(args, col_tiles, dev, cus, cap, stream);
+    } else {
+      return SRI_EUNSUPPORTED;
+    }
+  }
   if constexpr (G::BM >= 128) {
     if (h->ascending) {                                           // rows > 512, plain apply (create_from_matrix)
       if (!dma || rank1 || args.qe != nullptr) return SRI_EUNSUPPORTED;

@@ -225,6 +225,8 @@ struct ApplyArgs {
   uint32_t tile_order;   // 0: workgroup b walks tiles b, b + grid, ...;  1: XCD-grouped walk (see the kernel); run() says whether it is allowed, launch() decides
   uint32_t tail_k;       // rows % 16: valid k's of the last chunk (0 = the last chunk is full)
   uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
+  double* y2;            // EPI_QB only: the position right-hand side b = R(q) e1 (main.cpp:121-140), 3 columns per rod, m/4 rods
+  size_t ldy2;           //   leading dimension of that panel; > rows_out when rows_out is odd (the last row pair is stored whole)
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
 };
 
@@ -413,7 +415,12 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           (t -> 4*(t&3) + (t>>2), applied to the X-fragment read address only) so that the four accumulator
 //           registers of a lane are the four components of ONE rod at one node; stores keep their shape.
 // ---------------------------------------------------------------------------------------------
-enum { EPI_NONE = 0, EPI_QUAT = 1 };
+//           EPI_QB (round 5) is the CLOSING product of a rod solve: the panel is 4 columns per rod like EPI_QUAT's, Q = A X - w xb^T is
+//           stored as it is (the plain epilogue's stores in the permuted column order) and, from the same accumulators, the
+//           position right-hand side b = R(q) e1 of main.cpp:121-140 (3 columns per rod, panel y2) — so that the confirmation
+//           pass behind it only READS.  Odd-row-count integration operators on the LDS-DMA path (DMA && RANK1 && TAIL: the
+//           rank-1 term is folded into the product, the accumulators ARE Q); no tips, no monitor.
+enum { EPI_NONE = 0, EPI_QUAT = 1, EPI_QB = 2 };
 
 template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false, bool LEAN = false>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
@@ -422,7 +429,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   static_assert(!STAMP && ABL == 0, "stamped / ablated instantiations are diagnostic scaffolding: build with -DSRI_DIAG (tools/apply_diag.hip)");
 #endif
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
-  static_assert(EPI == EPI_NONE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
+  static_assert(EPI != EPI_QB || (DMA && TAIL && G::STRIP == 0), "EPI_QB: odd-row-count operators on the LDS-DMA path (the rank-1 term rides in the product)");
+  static_assert(EPI != EPI_QUAT || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
   // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // conflict-free instead.
   // With the ascending k order the X fragments are 8-byte reads, served in two 32-lane halves that each cover all 16
   // columns of the tile in either column order: & 7 is conflict-free for both.
-  constexpr int SWZ = (EPI == EPI_QUAT && !ASCK) ? 6 : 7;
+  constexpr int SWZ = (EPI != EPI_NONE && !ASCK) ? 6 : 7;
   constexpr bool FOLD = RANK1 && (TAIL || !DMA);
   constexpr bool RANK1_EPI = RANK1 && !FOLD;
   constexpr bool XBUF = FOLD && DMA;                  // x_base rides through the LDS side buffer (Geo::XB_BYTES)
@@ -799,10 +807,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // ... and of the fused quaternion epilogue's: this lane's rod is 4g columns in, its component r one column further each
   uint32_t ylane_q = 4u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
   asm volatile("" : "+v"(ylane_q));
+  // ... and of EPI_QB's second panel: rod g of the group is 3g columns in
+  [[maybe_unused]] uint32_t ylane_b = 0;
+  if constexpr (EPI == EPI_QB) {
+    ylane_b = 3u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy2 * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
+    asm volatile("" : "+v"(ylane_b));
+  }
   // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
   // column of the 16-column tile this lane feeds to the MFMA as column index c (identity unless EPI_QUAT)
-  const int cs = EPI == EPI_QUAT ? 4 * (c & 3) + (c >> 2) : c;
+  const int cs = EPI != EPI_NONE ? 4 * (c & 3) + (c >> 2) : c;
   const int sig = ((cs >> 1) & SWZ);
   const int x_off = G::A_BYTES + (wn * TN * 16 + cs) * X_ROW_BYTES;
   // Ascending k: one 8-byte X read per MFMA.  Seen as plain loads 2 KiB apart, the reads of two column tiles are paired
@@ -1115,6 +1129,99 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
     return full;
   };
+  // EPI_QB: acc[tm][tn][r] = Q[row][rod (wn TN + tn) 4 + g][r] as in EPI_QUAT (FOLD: the rank-1 term is already in the product).  Per
+  // (rod group tn, row pair t) a wave issues 4 stores of Q and 3 of b = R(q) e1 (Eigen's toRotationMatrix, first column: the
+  // operation order of position_rhs_kernel, sri_rod.hip, so that the bits are those of the unfused composition): 7 TM TN / 2 = 56
+  // per tile, which the counted waits know (TILE_STORES).  Q goes to the caller's panel, whose last row may not exist: the wave that
+  // holds it stores its last pair shifted up by a row like the plain epilogue; b goes to a panel with room for the whole pair.
+  auto store_tile_qb = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    const ApplyArgs q = SRI_ARGS_HERE;
+    const uint32_t rb_c = tile / q.col_tiles;
+    const size_t col0_c = static_cast<size_t>(tile % q.col_tiles) * G::BN;
+    const uint32_t row_base = rb_c * G::BM + wm * (TM * 16) + 2 * c;
+    const size_t col_base4 = col0_c + wn * (TN * 16) + 4 * g;
+    auto position_rhs = [](double w, double x, double y, double z, double (&b)[3]) __attribute__((always_inline)) {
+      const double ty = 2 * y, tz = 2 * z;
+      const double twy = ty * w, twz = tz * w, txy = ty * x, txz = tz * x, tyy = ty * y, tzz = tz * z;
+      b[0] = 1 - (tyy + tzz);
+      b[1] = txy + twz;
+      b[2] = txz - twy;
+    };
+    if constexpr (SRI_STORE_SADDR != 0) {
+      if ((col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + 1)) {
+        const bool odd = rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1;   // wave-uniform: this wave's last row does not exist
+        const size_t ldy8 = q.ldy * sizeof(double), ldb8 = q.ldy2 * sizeof(double);
+        const size_t row_off = (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
+        char* const ybase = reinterpret_cast<char*>(q.y) + (col0_c + wn * (TN * 16)) * ldy8 + row_off;
+        char* const bbase = reinterpret_cast<char*>(q.y2) + ((col0_c + wn * (TN * 16)) / 4 * 3) * ldb8 + row_off;
+        auto emit = [&](auto odd_tag) __attribute__((always_inline)) {
+          constexpr bool ODD = decltype(odd_tag)::value;
+          char* ct = ybase;                                      // first Q column of rod group tn (uniform)
+          char* bt = bbase;                                      // first b column of it
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            if (tn != 0) {
+              ct += 16 * ldy8;
+              bt += 12 * ldb8;
+              asm volatile("" : "+s"(ct), "+s"(bt));
+            }
+            static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
+              constexpr int t = decltype(tc)::value;
+              double b[2][3];
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+                position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b[e]);
+              char* cb = ct;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (r != 0) {
+                  cb += ldy8;
+                  asm volatile("" : "+s"(cb));
+                }
+                if constexpr (ODD && t == TM / 2 - 1) {
+                  const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
+                  store16_sv<false, 256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
+                } else {
+                  store16_sv<false, 256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
+                }
+              }
+              char* bb = bt;
+#pragma unroll
+              for (int a = 0; a < 3; ++a) {
+                if (a != 0) {
+                  bb += ldb8;
+                  asm volatile("" : "+s"(bb));
+                }
+                store16_sv<false, 256 * t>(bb, ylane_b, d2{b[0][a], b[1][a]});
+              }
+            });
+          }
+        };
+        if (odd) emit(std::true_type{}); else emit(std::false_type{});
+        return true;
+      }
+    }
+    // ragged tiles, partial row blocks: element by element, uncounted (the caller drains)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const size_t col = col_base4 + tn * 16;
+      if (col >= q.m) continue;                                  // m is a multiple of 4: a rod is in or out as a whole
+#pragma unroll
+      for (int t = 0; t < TM / 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t row = row_base + 32 * t + e;
+          if (row >= q.rows_out) continue;
+          double b[3];
+          position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q.y[(col + r) * q.ldy + row] = acc[2 * t + e][tn][r];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) q.y2[(col / 4 * 3 + a) * q.ldy2 + row] = b[a];
+        }
+    }
+    return false;
+  };
   // The strip's 16 x 16 tile of this wave: lane (c, g) holds row BM + c of the columns g, g + 4, g + 8, g + 12 of the wave's
   // column tile wm — four 8-byte stores, 128 contiguous bytes per column.  `counted`: every column exists and the wave is on
   // the counted-store path: exactly four store INSTRUCTIONS must be issued whatever the number of valid rows (the stage waits
@@ -1167,6 +1274,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && (!RANK1_EPI || R1X) && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
+    if constexpr (EPI == EPI_QB) return store_tile_qb(tile);
     const ApplyArgs q = SRI_ARGS_HERE;
     uint32_t rb_c = tile / q.col_tiles;
     double* yp_ = q.y;
@@ -1334,7 +1442,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // LDS hazards are those of the unshifted stream because every read of slot s-1 still precedes barrier(s).
   constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
   // (the fused quaternion epilogue of an odd-row-count operator issues the last row pair as two masked instructions: TN * 4 more)
-  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0);
+  // (EPI_QB: three more columns per rod — 7 stores where the plain epilogue has 4)
+  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0) + (EPI == EPI_QB ? G::NSTORE * 3 / 4 : 0);
   static_assert((AHEAD - 1) * G::DMA_PER_WAVE + TILE_STORES <= 63, "counted vmcnt must fit the 6-bit counter");
   constexpr int W_BOUNDARY = W_STEADY + TILE_STORES;        // ... plus one full tile's stores
   static_assert(AHEAD == 1 || AHEAD == 2, "the wait counts assume one or two stages in flight");
@@ -1641,7 +1750,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #ifndef SRI_QUAT_EARLY_READ
 #define SRI_QUAT_EARLY_READ 0        // A/B knob (profiles/r05_ab_fused_step_read_placement.log): 1 = round 4's placement in the fused step too
 #endif
-      constexpr bool LATE_READ = EPI == EPI_QUAT && SRI_QUAT_EARLY_READ == 0;
+      constexpr bool LATE_READ = EPI != EPI_NONE && SRI_QUAT_EARLY_READ == 0;
       if constexpr (!LATE_READ) read_pair(next_slot, 0, pa, pb);
       mfma_groups(qa, qb, I1{}, IG{}, piece, PT{});
       flush_pieces(piece, PT{});

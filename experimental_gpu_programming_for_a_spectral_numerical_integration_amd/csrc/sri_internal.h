@@ -62,6 +62,12 @@ int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const doub
                         double* dG_next, size_t ldn, size_t M, double* d_tips, void* stream, uint32_t* partials = nullptr);
 // a rows_out x kdim operator with rank-1 weights (kdim >= 16, kdim % 16 != 0), usable with integrate_quat_step only — sri_apply.hip
 int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t kdim, const double* A, size_t lda, const double* w, int device);
+// The CLOSING product of a rod solve (sri_rod.hip): Q = Dn_NN^-1 G - w x_base^T as sri_integrate forms it, and from the same
+// accumulators the position right-hand side b = R(q) e1 of main.cpp:121-140 (dB: rows x 3 M / 4, ldb > rows when rows is odd) — one
+// launch (EPI_QB), the bits of sri_integrate followed by position_rhs_kernel.  M a multiple of 4.  SRI_EUNSUPPORTED where the handle
+// has no such variant (row counts that are multiples of 16, operators outside the 256-row tile geometry): the caller composes the two.
+int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, double* dQ, size_t ldq, double* dB,
+                                size_t ldb, size_t M, void* stream);
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 int ivp_weights(const sri_apply_t* h, double* w_host);   // w = Dn_NN^-1 Dn_IN as the handle applies it (rows doubles); `device` current

@@ -340,6 +340,8 @@ struct sri_rod_handle {
   size_t pos_ldr = 0;
   double pos_r0[3] = {0.0, 0.0, 0.0};
   bool positions_done = false;
+  bool fused_position_rhs = true;         // sri_rod_integrate: the closing product also emits b = R(q) e1 where the handle has that variant
+                                          // (SRI_ROD_OPT_FUSED_POSITION_RHS); the confirmation pass then only reads
 };
 
 namespace sri {
@@ -518,6 +520,10 @@ int sri_rod_set_predictor(sri_rod_t* h, int enable) {
 
 int sri_rod_set_option(sri_rod_t* h, int option, long value) {
   if (h == nullptr || h->integ == nullptr) return SRI_EINVAL;
+  if (option == SRI_ROD_OPT_FUSED_POSITION_RHS) {
+    h->fused_position_rhs = value != 0;
+    return SRI_OK;
+  }
   if (option == SRI_ROD_OPT_FIRST_SWEEP_CHECK) {
     h->first_sweep_check = value != 0;
     h->first_sweep_failed_tol = h->second_sweep_failed_tol = 0.0;
@@ -743,11 +749,23 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // The whole-panel criterion for the iterate in dQ, formed from the right-hand side `g`: with d = 1/2 A(K) Q - g the next update
   // of Q is Dn_NN^-1 d, and upd = min(max |d|, max_i ||row i||_2 * max_col ||d_col||_2) bounds its largest entry (||Dn_NN^-1||_inf
   // = 1; Cauchy-Schwarz) — both from ONE pass (confirm_fixed_point_kernel), which also leaves the position right-hand side.
+  // The closing product: Q from the right-hand side `g` — and, for sri_rod_integrate, the position right-hand side from the same
+  // accumulators where the handle has that kernel variant (b_emitted; otherwise the confirmation pass writes it)
+  bool b_emitted = false;
+  auto closing_product = [&](const double* g) -> int {
+    b_emitted = false;
+    if (h->emit_position_rhs && h->fused_position_rhs) {
+      const int r = sri::integrate_with_position_rhs(h->integ, g, ldw, h->d_xb4, dQ, ldq, h->d_B, ldw, cols, stream);
+      if (r == SRI_OK) b_emitted = true;
+      if (r != SRI_EUNSUPPORTED) return r;
+    }
+    return sri_integrate(h->integ, g, ldw, h->d_xb4, dQ, ldq, cols, stream);
+  };
   auto confirm = [&](const double* g, bool positions_behind = false) -> int {
     ROD_HIP(hipMemsetAsync(h->d_diff, 0, 2 * sizeof(unsigned long long), stream));
     const unsigned blocks = static_cast<unsigned>(std::min<size_t>(2048, (rods + 3) / 4));                 // one wave per rod
     ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(blocks), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, g, ldw,
-                       h->d_diff, h->emit_position_rhs ? h->d_B : static_cast<double*>(nullptr), ldw, static_cast<double*>(nullptr), ldw));
+                       h->d_diff, (h->emit_position_rhs && !b_emitted) ? h->d_B : static_cast<double*>(nullptr), ldw, static_cast<double*>(nullptr), ldw));
     ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     h->positions_done = false;
     if (positions_behind && h->emit_position_rhs && h->pos_dR != nullptr) {
@@ -772,7 +790,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   auto finish = [&]() -> int {
     cur = bufs[it & 1];
     nxt = bufs[(it + 1) & 1];
-    int r = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
+    int r = closing_product(cur);
     if (r != SRI_OK) return r;
     return confirm(cur);
   };
@@ -786,7 +804,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // device-driven loop below run, from G^0, as if nothing had happened.
   if (predicted && h->first_sweep_check && tol > h->second_sweep_failed_tol) {
     if (tol > h->first_sweep_failed_tol) {
-      rc = sri_integrate(h->integ, cur, ldw, h->d_xb4, dQ, ldq, cols, stream);
+      rc = closing_product(cur);
       if (rc != SRI_OK) return rc;
       rc = confirm(cur, true);
       if (rc != SRI_OK) return rc;
@@ -801,7 +819,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     if (max_iter >= 2) {
       sri::QuatEpilogue epi{d_qe, h->d_leg};
       rc = sri::integrate_quat_step(h->integ, cur, ldw, h->d_xb4, epi, nxt, ldw, cols, nullptr, stream);
-      if (rc == SRI_OK) rc = sri_integrate(h->integ, nxt, ldw, h->d_xb4, dQ, ldq, cols, stream);
+      if (rc == SRI_OK) rc = closing_product(nxt);
       if (rc != SRI_OK) return rc;
       rc = confirm(nxt, true);
       if (rc != SRI_OK) return rc;

@@ -261,6 +261,10 @@ int sri_rod_set_predictor(sri_rod_t *h, int enable);
                                              plain product and evaluates the whole-panel criterion; only if that fails does the
                                              fused fixed-point loop run (and the handle does not retry at or below that tol).
                                              0: always the loop.  Same fixed point, same criterion either way               */
+#define SRI_ROD_OPT_FUSED_POSITION_RHS 101 /* 1 (default): in sri_rod_integrate the product that closes the quaternion solve also
+                                              writes the position right-hand side R(q) e1 from its accumulators where the handle
+                                              has that kernel variant (odd row counts in the 256-row tile geometry: N = 256, 512, 1024 ...); 0: a separate pass
+                                              writes it.  Same bits                                                           */
 int sri_rod_set_option(sri_rod_t *h, int option, long value);
 
 /* Strain field K(X_i) = Phi(X_i) qe at the unknown nodes (utilities.h:49-67, main.cpp:69):

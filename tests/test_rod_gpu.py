@@ -389,6 +389,31 @@ def test_first_sweep_check_is_a_rigorous_bound_and_the_same_fixed_point(sri, ora
         assert it_a == 1, (it_a, upd_a)                              # (the measured figures: Cauchy-Schwarz bound 1 ... 4e-15 after one sweep)
 
 
+@pytest.mark.parametrize("n,rods", [(256, 700), (256, 4096), (128, 900), (512, 300), (1024, 100), (300, 333), (200, 500), (257, 400), (100, 64)])
+def test_closing_product_emits_the_position_rhs_with_the_bits_of_the_separate_pass(sri, n, rods):
+    """Round 5 (EPI_QB): in sri_rod_integrate the product that closes the quaternion solve also writes b = R(q) e1 from its
+    accumulators — odd row counts in the 256-row tile geometry; other grids (N = 257: 256 rows; N = 128, 300: 128-row tiles) fall back to the pass — so
+    that the confirmation pass only reads.  The positions must be, bit for bit, what the unfused composition gives from the same
+    quaternions (position_rhs kernel + integration), Q and the criterion must not depend on the switch, and full tiles, ragged
+    last tiles, partial row blocks (199 rows in a 256-row block) and several row blocks all take part."""
+    import torch
+
+    qe = torch.from_numpy(_qe_batch(rods, seed=31 * n + rods)).cuda()
+    q_init, r_init = [0.6, 0.0, 0.8, 0.0], [1.0, -2.0, 0.5]
+    rod = sri.RodIntegrator(n)
+    out = []
+    for fused in (1, 0):
+        rod.set_option(sri.ROD_OPT_FUSED_POSITION_RHS, fused)
+        Q, R = rod.integrate(qe, q_init=q_init, r_init=r_init)
+        torch.cuda.synchronize()
+        out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert out[0][2:] == out[1][2:]
+    R2 = rod.integrate_positions(out[0][0], r_init=r_init)               # the unfused composition, from the same quaternions
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][1], R2)
+
+
 @pytest.mark.parametrize("n,rods", [(32, 700), (48, 333), (64, 1500), (20, 64), (63, 40)])
 def test_on_chip_coarse_start_matches_oracle_and_plain_start(sri, oracle, n, rods):
     """16 < N <= 64 (round 3): the on-chip pipeline first solves the rods on a coarse grid inside the same launch — 16 nodes

@@ -18,6 +18,12 @@ python bench.py --config 2 --steps 20000 --warmup 1000 > gpurun_out/${tag}_bench
 python bench.py --config 5 --steps 1000 > gpurun_out/${tag}_bench_cfg5.json 2>/dev/null; echo "bench cfg5 rc=$?"
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_driver_form.json 2>/dev/null; echo "bench driver form rc=$?"
 fi
+if [ "$part" = "c" ]; then
+# round 5: the two grid sizes between the BASELINE configs that sit furthest below their roofline, with the prescribed PMC passes
+PROFILE_STEPS=200 tools/profile_bench.sh ${tag}_n128 --n 128 --rods 131072 > gpurun_out/prof_${tag}_n128.log 2>&1; echo "profile n128 rc=$?"
+PROFILE_STEPS=200 tools/profile_bench.sh ${tag}_n96 --n 96 --rods 174752 > gpurun_out/prof_${tag}_n96.log 2>&1; echo "profile n96 rc=$?"
+bash tools/sweep_n.sh ${tag} > gpurun_out/sweep_${tag}.log 2>&1; echo "sweep rc=$?"
+fi
 if [ "$part" = "lines" ]; then
 python bench.py > gpurun_out/${tag}_bench_n256.json 2> gpurun_out/${tag}_bench_n256.err; echo "bench cfg3 rc=$?"
 python bench.py --config 2 --steps 20000 --warmup 1000 > gpurun_out/${tag}_bench_cfg2.json 2>/dev/null; echo "bench cfg2 rc=$?"
