@@ -91,8 +91,10 @@ int resident_create(uint32_t n, int device, int num_cus, ResidentRod** out, cons
 int resident_destroy(ResidentRod* h);
 int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
                        size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
-                       double* last_update_out, void* stream, bool coarse_start = true);   // coarse_start: grids of > 16 nodes begin
-                                                                                            // from an on-chip 16-node solution
+                       double* last_update_out, void* stream, bool coarse_start = true,    // coarse_start: grids of > 16 nodes begin
+                       bool defer_stats = false);                                           // from an on-chip 16-node solution;
+                                                                                            // defer_stats: do not wait (resident_collect)
+int resident_collect(ResidentRod* h, uint32_t* iters_out, double* last_update_out, void* stream);
 
 // ---- fragment geometry shared by the host packer and the kernel (sri_apply.hip) ---------------
 // One v_mfma_f64_16x16x4_f64 computes D[i][j] += sum_k P[i][k] Q[k][j] (i, j < 16, k < 4); lane l feeds

@@ -165,10 +165,25 @@ __global__ void fold_partials_kernel(const double* __restrict__ partial, uint32_
 // sums of squares are a wave reduction; the nine strain coefficients are scalar loads.  Reads 8 doubles per rod and node.
 // Optional by-products, since Q is in registers anyway: the position right-hand side b = R(q) e1 of every node (B != nullptr;
 // same arithmetic as position_rhs_kernel) and the next right-hand side 1/2 A(K) Q itself (Gout != nullptr).
+// (Round 5, second cut: the first wave-per-rod version issued its loads four at a time behind `vmcnt(0)` waits — 134 registers,
+// three waves per SIMD, 2.8 TB/s.  Now: the Legendre factors of all nodes sit in LDS once per block, a wave takes 4 x 64 nodes of
+// its rod per step and issues all 32 loads of the step before it touches any, the optional outputs are template parameters.)
+// result: two slots of {bits of max |d|, bits of max column sum of squares}; the launch accumulates into slot `slot` and block 0
+// clears the OTHER one for the next launch (no memset between launches).  Dynamic shared memory: 2 * m doubles.
+template <bool WRITE_B, bool WRITE_G>
 __global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, size_t rods, const double* __restrict__ nodes, const double* __restrict__ qe,
                                                                   const double* __restrict__ Q, size_t ldq, const double* __restrict__ G, size_t ldg,
-                                                                  unsigned long long* result, double* __restrict__ B, size_t ldb,
+                                                                  unsigned long long* result, uint32_t slot, double* __restrict__ B, size_t ldb,
                                                                   double* __restrict__ Gout, size_t ldo) {
+  extern __shared__ double legendre[];                          // P1 of node i at [i], P2 at [m + i]
+  for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
+    const double P0 = 1.0, P1 = x;
+    legendre[i] = P1;
+    legendre[m + i] = ((2 * 1 + 1) * x * P1 - 1 * P0) / (1 + 1);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) result[2 * (slot ^ 1u) + threadIdx.x] = 0ull;
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const size_t waves = (static_cast<size_t>(gridDim.x) * blockDim.x) >> 6;
   double dmax = 0.0, ssmax = 0.0;
@@ -180,43 +195,53 @@ __global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, si
     double q9[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) q9[k] = q[k];
+    const double* Qr = Q + rod * 4 * ldq;
+    const double* Gr = G + rod * 4 * ldg;
     double ss[4] = {0.0, 0.0, 0.0, 0.0};
-#ifndef SRI_CONFIRM_NT
-#define SRI_CONFIRM_NT 0             // A/B knob: read-once / write-once accesses of the pass as non-temporal (measured: 1.814-1.835 ms against 1.813-1.827 plain at N = 256 — nothing)
-#endif
-#pragma unroll 4
-    for (uint32_t i = lane; i < m; i += 64u) {
-      const double x = (2 * nodes[i] - (1.0 + 0.0)) / (1.0 - 0.0);
-      const double P0 = 1.0, P1 = x;
-      const double P2 = ((2 * 1 + 1) * x * P1 - 1 * P0) / (1 + 1);
-      double hk[3];
+    for (uint32_t base = 0; base < m; base += 256u) {
+      double qv[4][4], gv[4][4];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        double s = P0 * q9[a * 3 + 0];
-        s = s + P1 * q9[a * 3 + 1];
-        s = s + P2 * q9[a * 3 + 2];
-        hk[a] = 0.5 * s;
-      }
-      auto ld1 = [](const double* p) __attribute__((always_inline)) { return SRI_CONFIRM_NT ? __builtin_nontemporal_load(p) : *p; };
-      auto st1 = [](double* p, double v) __attribute__((always_inline)) { if (SRI_CONFIRM_NT) __builtin_nontemporal_store(v, p); else *p = v; };
-      const double w = ld1(&Q[(rod * 4 + 0) * ldq + i]), x4 = ld1(&Q[(rod * 4 + 1) * ldq + i]);
-      const double y = ld1(&Q[(rod * 4 + 2) * ldq + i]), z = ld1(&Q[(rod * 4 + 3) * ldq + i]);
-      double gq[4];
-      quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
-      if (B != nullptr) {
-        const double ty = 2 * y, tz = 2 * z;
-        const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
-        st1(&B[(rod * 3 + 0) * ldb + i], 1 - (tyy + tzz));
-        st1(&B[(rod * 3 + 1) * ldb + i], txy + twz);
-        st1(&B[(rod * 3 + 2) * ldb + i], txz - twy);
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = base + 64u * u + lane;
+        const uint32_t ic = i < m ? i : m - 1;                   // (lanes past the last node re-read it: every load is in bounds)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          qv[u][a] = Qr[a * ldq + ic];
+          gv[u][a] = Gr[a * ldg + ic];
+        }
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        if (Gout != nullptr) Gout[(rod * 4 + a) * ldo + i] = gq[a];
-        const double diff = gq[a] - ld1(&G[(rod * 4 + a) * ldg + i]);
-        const double d = fabs(diff);
-        dmax = d > dmax || d != d ? d : dmax;
-        ss[a] = __builtin_fma(diff, diff, ss[a]);
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = base + 64u * u + lane;
+        if (i < m) {
+          const double P1 = legendre[i], P2 = legendre[m + i];
+          double hk[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double s = 1.0 * q9[a * 3 + 0];
+            s = s + P1 * q9[a * 3 + 1];
+            s = s + P2 * q9[a * 3 + 2];
+            hk[a] = 0.5 * s;
+          }
+          const double w = qv[u][0], x4 = qv[u][1], y = qv[u][2], z = qv[u][3];
+          double gq[4];
+          quat_rhs_half(hk[0], hk[1], hk[2], w, x4, y, z, gq);
+          if constexpr (WRITE_B) {
+            const double ty = 2 * y, tz = 2 * z;
+            const double twy = ty * w, twz = tz * w, txy = ty * x4, txz = tz * x4, tyy = ty * y, tzz = tz * z;
+            B[(rod * 3 + 0) * ldb + i] = 1 - (tyy + tzz);
+            B[(rod * 3 + 1) * ldb + i] = txy + twz;
+            B[(rod * 3 + 2) * ldb + i] = txz - twy;
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            if constexpr (WRITE_G) Gout[(rod * 4 + a) * ldo + i] = gq[a];
+            const double diff = gq[a] - gv[u][a];
+            const double d = fabs(diff);
+            dmax = d > dmax || d != d ? d : dmax;
+            ss[a] = __builtin_fma(diff, diff, ss[a]);
+          }
+        }
       }
     }
 #pragma unroll
@@ -232,8 +257,8 @@ __global__ __launch_bounds__(256) void confirm_fixed_point_kernel(uint32_t m, si
   }
   if (lane == 0) {
     const unsigned long long nan_bits = 0x7ff8000000000000ull;
-    atomicMax(result, (dmax != dmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(dmax)));
-    atomicMax(result + 1, (ssmax != ssmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(ssmax)));
+    atomicMax(result + 2 * slot, (dmax != dmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(dmax)));
+    atomicMax(result + 2 * slot + 1, (ssmax != ssmax) ? nan_bits : static_cast<unsigned long long>(__double_as_longlong(ssmax)));
   }
 }
 
@@ -312,8 +337,11 @@ struct sri_rod_handle {
   // workspace, grown on demand
   size_t cap_rods = 0;
   double *d_K = nullptr, *d_G = nullptr, *d_Qa = nullptr, *d_B = nullptr, *d_xb4 = nullptr, *d_xb3 = nullptr;
+  size_t xb4_rods = 0, xb3_rods = 0;     // what d_xb4 / d_xb3 hold: the base value of every column for that many rods and these
+  double xb4_val[4] = {0, 0, 0, 0}, xb3_val[3] = {0, 0, 0};   //   q_init / r_init (0 rods: nothing) — refilled only when either changes
   double* d_tips = nullptr;              // 2 x (4*rods): tip-node values of the last two iterates
-  unsigned long long* d_diff = nullptr;   // two slots (ping-pong with the pipelined read-back)
+  unsigned long long* d_diff = nullptr;   // two slots of two words: the confirmation pass accumulates into one and clears the other
+  uint32_t diff_slot = 0;
   double* d_partial = nullptr;            // cap_partial: per-workgroup tip-update maxima of the fused step
   uint32_t cap_partial = 0;
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
@@ -351,6 +379,7 @@ static int ensure_workspace(sri_rod_handle* h, size_t rods) {
   auto rel = [&](double*& p) { if (p) (void)hipFree(p); p = nullptr; };
   rel(h->d_K); rel(h->d_G); rel(h->d_Qa); rel(h->d_B); rel(h->d_xb4); rel(h->d_xb3); rel(h->d_tips);
   h->cap_rods = 0;
+  h->xb4_rods = h->xb3_rods = 0;
   const size_t m = h->ldw;
   if (hipMalloc(&h->d_K, sizeof(double) * m * 3 * rods) != hipSuccess) return SRI_ENOMEM;
   if (hipMalloc(&h->d_G, sizeof(double) * m * 4 * rods) != hipSuccess) return SRI_ENOMEM;
@@ -428,7 +457,8 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
       hipMemcpy(h->d_nodes, x.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_leg, sizeof(double) * leg.size()) != hipSuccess ||
       hipMemcpy(h->d_leg, leg.data(), sizeof(double) * leg.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc(&h->d_diff, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&h->d_diff, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_diff, 0, 4 * sizeof(unsigned long long)) != hipSuccess ||
       (h->cap_partial = sri::max_partials(integ)) == 0 ||
       hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial * 2) != hipSuccess ||     // two steps' worth: step k folds step k-1's
       hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess ||
@@ -643,9 +673,13 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   const uint32_t m = h->m;
   const size_t cols = 4 * rods;
 
-  // xb = the base value of every column
-  ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
-                     qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4));
+  // xb = the base value of every column (kept from the last call when neither the batch size nor q_init has changed)
+  if (h->xb4_rods != rods || std::memcmp(h->xb4_val, qi, sizeof(h->xb4_val)) != 0) {
+    ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                       qi[2], qi[3], static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb4));
+    h->xb4_rods = rods;
+    std::memcpy(h->xb4_val, qi, sizeof(h->xb4_val));
+  }
   const size_t ldw = h->ldw;
   double* cur = h->d_G;        // right-hand sides ping-pong between two workspace panels (ld = ldw)
   double* nxt = h->d_Qa;
@@ -655,14 +689,19 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // fixed point of the FINE system, monitored and confirmed exactly as without the predictor; if the coarse solve
   // fails (NaN), the plain start Q^0 = q_init is used.
   bool predicted = false;
+  // (where the settling sweeps below will run, the coarse solve's statistics are not waited for: coarse solve, prolongation, sweep,
+  // bound and position product form ONE enqueued sequence with ONE host wait at its end; a coarse solve that produced NaN is
+  // found out there and the solve begins again from q_init)
+  bool coarse_deferred = false;
   if (h->coarse != nullptr && h->use_predictor) {
     constexpr uint32_t mc = sri::kCoarseN - 1;
     double* dQc = h->d_B;                                      // free until the position step: m*3 >= mc*4 doubles per rod
     uint32_t itc = 0;
     double updc = 0.0;
     const uint32_t coarse_iters = max_iter < 100 ? max_iter : 100;
+    coarse_deferred = h->first_sweep_check && tol > h->second_sweep_failed_tol && (tol > h->first_sweep_failed_tol || max_iter >= 2);
     int rcc = sri::resident_integrate(h->coarse, d_qe, rods, qi, nullptr, dQc, mc, nullptr, 0, 0.25 * tol, coarse_iters, &itc, &updc,
-                                      stream_);
+                                      stream_, true, coarse_deferred);
     if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
       if (h->prolong != nullptr) {
         sri::QuatEpilogue epi{d_qe, h->d_leg};
@@ -678,13 +717,17 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       return rcc;
     }
   }
-  if (!predicted) {
-    // Q^0 = q_init at every node (in the caller's panel), G^0 = 1/2 A(K) Q^0
-    rc = sri_rod_strain_field(h, d_qe, rods, h->d_K, ldw, stream);
-    if (rc != SRI_OK) return rc;
+  // Q^0 = q_init at every node (in the caller's panel), G^0 = 1/2 A(K) Q^0
+  auto plain_start = [&]() -> int {
+    int r = sri_rod_strain_field(h, d_qe, rods, h->d_K, ldw, stream);
+    if (r != SRI_OK) return r;
     ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols * m, 256)), dim3(256), 0, stream, m, cols, 4u,
                        qi[0], qi[1], qi[2], qi[3], dQ, ldq, static_cast<double*>(nullptr)));
-    rc = sri_rod_quaternion_rhs(h, h->d_K, ldw, dQ, ldq, rods, cur, ldw, stream);
+    return sri_rod_quaternion_rhs(h, h->d_K, ldw, dQ, ldq, rods, cur, ldw, stream);
+  };
+  if (!predicted) {
+    coarse_deferred = false;
+    rc = plain_start();
     if (rc != SRI_OK) return rc;
   }
 
@@ -703,7 +746,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // ||Dn_NN^-1||_inf = 1.  Should that ever fail, the loop resumes with a 4x tighter tip tolerance.
   // (after a predicted start the loop usually stops after ONE real step: chunks of one keep the launches past convergence at
   // two — the step that folds and decides, and the one already in flight — instead of three with chunks of two)
-  const uint32_t kChunk = predicted ? 1u : 8u;                  // iterations enqueued per read-back of the loop state
+  uint32_t kChunk = predicted ? 1u : 8u;                        // iterations enqueued per read-back of the loop state
   double* bufs[2] = {cur, nxt};                                 // iteration k reads bufs[k & 1], writes bufs[(k + 1) & 1]
   unsigned long long* const h_state = h->h_state;               // 2 slots x 4 words, pinned; owned by the handle
   hipEvent_t* const done = h->done;
@@ -712,7 +755,6 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
                        qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr)));
   }
-  ROD_HIP(hipMemsetAsync(h->d_state, 0, 4 * sizeof(unsigned long long), stream));
   // From the predictor's start the error is rounding-level noise spread over the whole rod, not a Picard transient that
   // dies last at the tip: the tip monitor alone is then a weaker proxy, so it is asked for a 4x smaller update (the
   // whole-panel confirmation below remains the criterion that counts).  Measured with the plain tolerance instead: no
@@ -762,18 +804,29 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     return sri_integrate(h->integ, g, ldw, h->d_xb4, dQ, ldq, cols, stream);
   };
   auto confirm = [&](const double* g, bool positions_behind = false) -> int {
-    ROD_HIP(hipMemsetAsync(h->d_diff, 0, 2 * sizeof(unsigned long long), stream));
     const unsigned blocks = static_cast<unsigned>(std::min<size_t>(2048, (rods + 3) / 4));                 // one wave per rod
-    ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel, dim3(blocks), dim3(256), 0, stream, m, rods, h->d_nodes, d_qe, dQ, ldq, g, ldw,
-                       h->d_diff, (h->emit_position_rhs && !b_emitted) ? h->d_B : static_cast<double*>(nullptr), ldw, static_cast<double*>(nullptr), ldw));
-    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    const size_t lds = 2 * static_cast<size_t>(m) * sizeof(double);                                       // (m <= 4095 fits 64 KiB)
+    const uint32_t slot = h->diff_slot;
+    h->diff_slot ^= 1u;                                                                                    // (this launch clears the other slot)
+    double* const nob = nullptr;
+    if (h->emit_position_rhs && !b_emitted)
+      ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel<true, false>, dim3(blocks), dim3(256), lds, stream, m, rods, h->d_nodes, d_qe, dQ,
+                         ldq, g, ldw, h->d_diff, slot, h->d_B, ldw, nob, ldw));
+    else
+      ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel<false, false>, dim3(blocks), dim3(256), lds, stream, m, rods, h->d_nodes, d_qe, dQ,
+                         ldq, g, ldw, h->d_diff, slot, nob, ldw, nob, ldw));
+    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff + 2 * slot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     h->positions_done = false;
     if (positions_behind && h->emit_position_rhs && h->pos_dR != nullptr) {
       // (sri_rod_integrate: the position product in front of the wait; if the bound then fails, the positions are formed again
       // from the final iterate)
       const size_t pcols = 3 * rods;
-      ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(pcols, 256)), dim3(256), 0, stream, 1u, pcols, 3u, h->pos_r0[0],
-                         h->pos_r0[1], h->pos_r0[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
+      if (h->xb3_rods != rods || std::memcmp(h->xb3_val, h->pos_r0, sizeof(h->xb3_val)) != 0) {
+        ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(pcols, 256)), dim3(256), 0, stream, 1u, pcols, 3u, h->pos_r0[0],
+                           h->pos_r0[1], h->pos_r0[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
+        h->xb3_rods = rods;
+        std::memcpy(h->xb3_val, h->pos_r0, sizeof(h->xb3_val));
+      }
       const int pr = sri_integrate(h->integ, h->d_B, ldw, h->d_xb3, h->pos_dR, h->pos_ldr, pcols, stream);       // main.cpp:172
       if (pr != SRI_OK) return pr;
       h->positions_done = true;
@@ -802,37 +855,61 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // one fused step and the closing product — and the bound is evaluated once, behind them; the tip monitor, which asks for a
   // quarter of the tolerance at ONE node and so runs four sweeps there, is not consulted.  Only if that fails too does the
   // device-driven loop below run, from G^0, as if nothing had happened.
+  // (the deferred statistics of the coarse solve, after the first wait: NaN there means the start is unusable)
+  auto coarse_start_failed = [&]() -> bool {
+    if (!coarse_deferred) return false;
+    coarse_deferred = false;
+    if (upd == upd) return false;                                 // a finite bound over the whole panel: the start was finite
+    uint32_t itc = 0;
+    double updc = 0.0;
+    (void)sri::resident_collect(h->coarse, &itc, &updc, stream);
+    return updc != updc;
+  };
+  bool restart_plain = false;
   if (predicted && h->first_sweep_check && tol > h->second_sweep_failed_tol) {
     if (tol > h->first_sweep_failed_tol) {
       rc = closing_product(cur);
       if (rc != SRI_OK) return rc;
       rc = confirm(cur, true);
       if (rc != SRI_OK) return rc;
-      if (upd <= tol) {
+      restart_plain = coarse_start_failed();
+      if (!restart_plain && upd <= tol) {
         if (iters_out) *iters_out = 1;
         if (last_update_out) *last_update_out = upd;
         return SRI_OK;
       }
       h->positions_done = false;
-      h->first_sweep_failed_tol = tol;
+      if (!restart_plain) h->first_sweep_failed_tol = tol;
     }
-    if (max_iter >= 2) {
+    if (!restart_plain && max_iter >= 2) {
       sri::QuatEpilogue epi{d_qe, h->d_leg};
       rc = sri::integrate_quat_step(h->integ, cur, ldw, h->d_xb4, epi, nxt, ldw, cols, nullptr, stream);
       if (rc == SRI_OK) rc = closing_product(nxt);
       if (rc != SRI_OK) return rc;
       rc = confirm(nxt, true);
       if (rc != SRI_OK) return rc;
-      if (upd <= tol) {
+      restart_plain = coarse_start_failed();
+      if (!restart_plain && upd <= tol) {
         if (iters_out) *iters_out = 1;                            // (as the loop counts: fused steps in front of the closing product)
         if (last_update_out) *last_update_out = upd;
         return SRI_OK;
       }
       h->positions_done = false;
-      h->second_sweep_failed_tol = tol;
+      if (!restart_plain) h->second_sweep_failed_tol = tol;
     }
     upd = INFINITY;
+    if (restart_plain) {
+      // the coarse solve produced NaN (found out at the first wait): begin again from Q = q_init, as a solve without predictor does
+      predicted = false;
+      rc = plain_start();
+      if (rc != SRI_OK) return rc;
+      kChunk = 8u;
+      tip_tol = tol;
+      ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 4u, qi[0], qi[1],
+                         qi[2], qi[3], h->d_tips + cols, static_cast<size_t>(1), static_cast<double*>(nullptr)));
+    }
   }
+  ROD_HIP(hipMemsetAsync(h->d_state, 0, 4 * sizeof(unsigned long long), stream));     // (the loop's state; the settling sweeps never read it)
   while (rc == SRI_OK) {
     // two chunks in flight; the state read back after chunk `slot` tells whether the loop has stopped
     uint32_t slot = 0;
@@ -878,6 +955,8 @@ int sri_rod_integrate_positions(sri_rod_t* h, const double* dQ, size_t ldq, size
   const size_t cols = 3 * rods;
   ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, stream, 1u, cols, 3u,
                      ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
+  h->xb3_rods = rods;
+  std::memcpy(h->xb3_val, ri, sizeof(h->xb3_val));
   rc = sri_rod_position_rhs(h, dQ, ldq, rods, h->d_B, h->ldw, stream);
   if (rc != SRI_OK) return rc;
   return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
@@ -920,6 +999,8 @@ int sri_rod_integrate(sri_rod_t* h, const double* d_qe, size_t rods, const doubl
   const size_t cols = 3 * rods;
   ROD_HIP(sri::launch_kernel(sri::fill_columns_kernel, dim3(sri::blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), 1u,
                      cols, 3u, ri[0], ri[1], ri[2], 0.0, static_cast<double*>(nullptr), static_cast<size_t>(1), h->d_xb3));
+  h->xb3_rods = rods;
+  std::memcpy(h->xb3_val, ri, sizeof(h->xb3_val));
   return sri_integrate(h->integ, h->d_B, h->ldw, h->d_xb3, dR, ldr, cols, stream);       // main.cpp:172
 }
 

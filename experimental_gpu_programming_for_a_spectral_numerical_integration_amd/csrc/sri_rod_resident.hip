@@ -466,6 +466,7 @@ struct ResidentRod {
   double* d_p1c = nullptr;
   double* d_stats = nullptr;
   double* h_stats = nullptr;      // pinned
+  uint32_t pending_blocks = 0;    // resident_integrate(..., defer_stats): entries of h_stats the caller collects after ITS wait
   uint32_t cap_blocks = 0;
 };
 
@@ -617,10 +618,35 @@ static int resident_create_parts(ResidentRod* h, uint32_t n, int device, int num
   return SRI_OK;
 }
 
-// Quaternions (dR == nullptr) or quaternions + positions of `rods` rods; synchronises the stream once (statistics).
+static void fold_stats(const ResidentRod* h, uint32_t blocks, uint32_t* iters_out, double* last_update_out) {
+  double its = 0.0, upd = 0.0;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    its = h->h_stats[2 * b] > its ? h->h_stats[2 * b] : its;
+    const double v = h->h_stats[2 * b + 1];
+    upd = (v > upd || v != v) ? v : upd;
+  }
+  if (iters_out) *iters_out = static_cast<uint32_t>(its);
+  if (last_update_out) *last_update_out = upd;
+}
+
+// The statistics of a launch enqueued with defer_stats (iterations, last update: NaN if any rod produced one): copied and waited for
+// HERE — the rod predictor only asks when the bound it reads at the end of its sequence is NaN
+int resident_collect(ResidentRod* h, uint32_t* iters_out, double* last_update_out, void* stream_) {
+  if (h == nullptr) return SRI_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RES_HIP(hipMemcpyAsync(h->h_stats, h->d_stats, 2 * sizeof(double) * h->pending_blocks, hipMemcpyDeviceToHost, stream));
+  RES_HIP(hipStreamSynchronize(stream));
+  fold_stats(h, h->pending_blocks, iters_out, last_update_out);
+  h->pending_blocks = 0;
+  return SRI_OK;
+}
+
+// Quaternions (dR == nullptr) or quaternions + positions of `rods` rods; synchronises the stream once (statistics) — unless
+// defer_stats: then the copy of the statistics is only enqueued (the rod predictor: no host round trip between the coarse solve
+// and the prolongation; resident_collect after the solve's one wait).
 int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const double* q_init, const double* r_init, double* dQ,
                        size_t ldq, double* dR, size_t ldr, double tol, uint32_t max_iter, uint32_t* iters_out,
-                       double* last_update_out, void* stream_, bool coarse_start) {
+                       double* last_update_out, void* stream_, bool coarse_start, bool defer_stats) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ResidentArgs args;
   args.apack = h->d_apack;
@@ -648,15 +674,14 @@ int resident_integrate(ResidentRod* h, const double* d_qe, size_t rods, const do
     default: rc = resident_launch<4, 1, 8>(h, args, stream, &blocks); break;   //  96 KiB: 1 WG (8 waves) per CU
   }
   if (rc != SRI_OK) return rc;
+  if (defer_stats) {
+    h->pending_blocks = blocks;
+    return SRI_OK;
+  }
   RES_HIP(hipMemcpyAsync(h->h_stats, h->d_stats, 2 * sizeof(double) * blocks, hipMemcpyDeviceToHost, stream));
   RES_HIP(hipStreamSynchronize(stream));
-  double its = 0.0, upd = 0.0;
-  for (uint32_t b = 0; b < blocks; ++b) {
-    its = h->h_stats[2 * b] > its ? h->h_stats[2 * b] : its;
-    const double v = h->h_stats[2 * b + 1];
-    upd = (v > upd || v != v) ? v : upd;
-  }
-  if (iters_out) *iters_out = static_cast<uint32_t>(its);
+  double upd = 0.0;
+  fold_stats(h, blocks, iters_out, &upd);
   if (last_update_out) *last_update_out = upd;
   return (upd <= tol) ? SRI_OK : SRI_ENOTCONVERGED;
 }
