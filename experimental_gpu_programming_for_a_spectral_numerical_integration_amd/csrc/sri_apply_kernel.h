@@ -1841,7 +1841,11 @@ using GeoTall = Geo<4, 2, 4, 4, 3>;   // BM 256 x BN 128, 8 waves, 144 KiB ring,
 // flight: 64 KiB) so that 2 WG share a CU and cover each other's waits: 64 < rows <= 128, and larger operators whose last 256-row block would be at most half full (create_from_matrix).  Measured at N = 128, 65 536 rods:
 // 0.138 ms against 0.146 ms for the previous 128 x 64 tile with three slots (+5.7 %).  (At N = 256, two row blocks, it is
 // 4 % behind the tall geometry: 0.531 vs 0.509 ms.)
-#ifndef SRI_GEO_MID_ALT
+#if defined(SRI_GEO_MID_ALT2)
+// A/B variant (round 5, N = 128): BM 128 x BN 64, four waves of 64 x 32, THREE ring slots (72 KiB): two workgroups per CU, each with two
+// stages in flight — what the verdict of round 4 asked to be measured ("128 x 64 tiles ... never with the stage in flight doubled")
+using GeoMid = Geo<2, 2, 4, 2, 3>;
+#elif !defined(SRI_GEO_MID_ALT)
 using GeoMid = Geo<2, 2, 4, 4, 2>;
 #else
 // A/B variant (round 5, N = 128): BM 128 x BN 256, EIGHT waves (2 x 4 of 64 x 64), three ring slots (144 KiB), 1 WG per CU — the tall

@@ -368,6 +368,10 @@ struct sri_rod_handle {
   size_t pos_ldr = 0;
   double pos_r0[3] = {0.0, 0.0, 0.0};
   bool positions_done = false;
+  double coarse_tol_factor = 2.0;         // the coarse solve of the predictor runs to this multiple of the tolerance (SRI_DEBUG=coarse_tol=<factor>: A/B).
+                                          // Round 5: 0.25 -> 2 — the whole-panel bound after the first fine sweep does not move (3.0e-15 at N = 256 for
+                                          // factors 0.25 ... 4: the last coarse sweeps contract factorially, the iterate is far better than its
+                                          // criterion says), the coarse solve loses its last sweeps (N = 128, 131 072 rods: 1.57 -> 1.46 ms)
   bool fused_position_rhs = true;         // sri_rod_integrate: the closing product also emits b = R(q) e1 where the handle has that variant
                                           // (SRI_ROD_OPT_FUSED_POSITION_RHS); the confirmation pass then only reads
 };
@@ -432,6 +436,10 @@ int sri_rod_create(sri_rod_t** out, uint32_t n, int device) {
   h->m = n - 1;
   h->ldw = (static_cast<size_t>(n - 1) + 15) & ~static_cast<size_t>(15);
   h->integ = integ;
+  {
+    const std::string f = sri::debug_option("coarse_tol");
+    if (!f.empty()) h->coarse_tol_factor = std::atof(f.c_str());
+  }
   try {                                                         // (host vectors below: no exception may cross the C ABI)
     rc = rod_create_parts(h, n, device, integ);
   } catch (const std::bad_alloc&) {
@@ -700,7 +708,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     double updc = 0.0;
     const uint32_t coarse_iters = max_iter < 100 ? max_iter : 100;
     coarse_deferred = h->first_sweep_check && tol > h->second_sweep_failed_tol && (tol > h->first_sweep_failed_tol || max_iter >= 2);
-    int rcc = sri::resident_integrate(h->coarse, d_qe, rods, qi, nullptr, dQc, mc, nullptr, 0, 0.25 * tol, coarse_iters, &itc, &updc,
+    int rcc = sri::resident_integrate(h->coarse, d_qe, rods, qi, nullptr, dQc, mc, nullptr, 0, h->coarse_tol_factor * tol, coarse_iters, &itc, &updc,
                                       stream_, true, coarse_deferred);
     if ((rcc == SRI_OK || rcc == SRI_ENOTCONVERGED) && updc == updc) {          // any finite iterate is a fine start
       if (h->prolong != nullptr) {
