@@ -139,7 +139,10 @@ struct Geo {
   static constexpr int WAVES_PER_SIMD = (NW + 3) / 4 < 2 ? 2 : (NW + 3) / 4;   // launch-bounds hint
   static constexpr int BM = WM * TM * 16;
   static constexpr int BN = WN * TN * 16;
-  static constexpr int A_ROWS = BM + 16 * STRIP;
+  // STRIP_ = 2 (round 5, "mini"): the same slab, stages and fragment reads, but the strip's tile carries FOUR rows (replicated in
+  // its four groups of four row slots) and its products run on v_mfma_f64_4x4x4_4b_f64 — 16.8 cycles instead of 64 per instruction
+  // (tools/mfma_f64_4x4_probe.hip): what the one leftover row of every N = 2^p + 1 grid (257, 513, 1025 rows) rides on
+  static constexpr int A_ROWS = BM + 16 * (STRIP != 0 ? 1 : 0);
   static constexpr int A_BYTES = A_ROWS * BK * 8;
   static constexpr int A_STRIP_OFFSET = BM * BK * 8;                    // the strip's tile inside a stage's operator slab
   static constexpr int A_PIECES = A_BYTES / 1024;
@@ -150,7 +153,7 @@ struct Geo {
   static constexpr int X_DMA_PER_WAVE = X_BYTES / 1024 / NW;
   static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
   static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
-  static constexpr int NSTORE = TM * TN * 2 + 4 * STRIP;                // Y store instructions per wave of a full tile (the strip: four of 8 bytes)
+  static constexpr int NSTORE = TM * TN * 2 + (STRIP == 1 ? 4 : (STRIP == 2 ? 1 : 0));   // Y store instructions per wave of a full tile (the strip: four of 8 bytes; the mini strip: one)
   // EPI_QUAT: the strain coefficients of a tile's rods (BN/4 rods x 9 doubles, contiguous in memory) travel with the
   // tile's first stage into a side buffer behind the ring; QE_BUFS tiles may be between "issued" and "epilogue read".
   // Each buffer also holds the Legendre factor P1 of the tile's BM rows.  Two buffers are enough when a tile has
@@ -846,6 +849,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // wave's own TN column tiles — and ONE set of fragments for it, read at the top of a k pair (behind the pair's own
   // fragments, which are in registers by then) and consumed after the last MFMA group of each k-step: 16 registers in all.
   d4 sacc = d4{0.0, 0.0, 0.0, 0.0};
+  double sacc1 = 0.0;                                          // STRIP == 2: D[column 4 (c >> 2) + g of the wave's strip tile][row BM + (c & 3)]
   d2 sfa = d2{0.0, 0.0}, sfb = d2{0.0, 0.0};
   const int s_a_off = G::A_STRIP_OFFSET + lane * 16;
   const int s_x_add = wm * 16 * X_ROW_BYTES;                    // from the wave's column tile 0 to its column tile wm
@@ -913,8 +917,15 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn][e], a[tm][e], acc[tm][tn], 0, 0, 0);
-      if constexpr (G::STRIP != 0) {
+      if constexpr (G::STRIP == 1) {
         if (tm == TM - 1) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(sfb[e], sfa[e], sacc, 0, 0, 0);   // k-step e of the strip
+      }
+      if constexpr (G::STRIP == 2) {
+        // Same operands, lane for lane: v_mfma_f64_4x4x4_4b_f64 routes them like the 16x16x4 (first operand [l & 15][l >> 4], second
+        // [l >> 4][l & 15]) but only multiplies inside the four 4 x 4 diagonal blocks — lane (c, g) receives D[4 (c >> 2) + g][c]:
+        // column 4 (c >> 2) + g against row SLOT c, which the host packs with operator row BM + (c & 3).  The same chain of four
+        // fused multiply-adds over the k slots (measured bit for bit: tools/mfma_f64_4x4_probe.hip).
+        if (tm == TM - 1) sacc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sfb[e], sfa[e], sacc1, 0, 0, 0);
       }
       if constexpr (PIECES) {
         if (piece < G::DMA_PER_WAVE) {
@@ -1228,7 +1239,39 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // count them), so the rows that do not exist are masked out through exec, not branched around.
   // `staged` (R1X epilogue): the rank-1 operands of this tile are in LDS (r1_side, buffer of the finished tile's parity)
   auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted, const char* staged = nullptr) __attribute__((always_inline)) {
-    if constexpr (G::STRIP != 0) {
+    if constexpr (G::STRIP == 2) {
+      // lane (c, g): row BM + (c & 3), column 4 (c >> 2) + g of the wave's strip column tile — ONE 8-byte store per lane; on the
+      // counted path it is issued by every wave whatever the number of valid rows (exec mask), like the strip's four
+      const uint32_t row = rb_c * G::BM + G::BM + (c & 3);
+      const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + 4 * (c >> 2) + g;
+      double v = sacc1;
+      if constexpr (RANK1_EPI) {
+        if (staged != nullptr) {
+          const double ws = *reinterpret_cast<const double*>(staged + G::R1_XB_BYTES + (G::BM + (c & 3)) * 8);
+          const double xs = *reinterpret_cast<const double*>(staged + (wn * (TN * 16) + wm * 16 + 4 * (c >> 2) + g) * 8);
+          v = __builtin_fma(-ws, xs, v);
+        } else if (row < q.rows_out && col_s < q.m) {
+          v = __builtin_fma(-q.w[row], q.xb[col_s], v);
+        }
+      }
+      if (counted) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t valid = q.rows_out - (rb_c * G::BM + G::BM);                    // 1 .. 4 rows of the mini strip exist
+        const uint32_t m4 = valid >= 4u ? 0xfu : ((1u << valid) - 1u);
+        const unsigned long long mask = 0x1111111111111111ull * m4;                    // row (c & 3) < valid, in every group of four lanes
+        const size_t ldy8 = q.ldy * sizeof(double);
+        char* const b0 = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16) + wm * 16) * ldy8 + (static_cast<size_t>(rb_c) * G::BM + G::BM) * sizeof(double);
+        const uint32_t off = (4u * (static_cast<uint32_t>(c) >> 2) + static_cast<uint32_t>(g)) * static_cast<uint32_t>(ldy8) + (static_cast<uint32_t>(c) & 3u) * 8u;
+        asm volatile("s_mov_b64 exec, %3\n\t"
+                     "global_store_dwordx2 %0, %1, %2\n\t"
+                     "s_mov_b64 exec, -1\n\ts_nop 1"
+                     ::"v"(off), "v"(v), "s"(b0), "s"(mask) : "memory");
+#endif
+      } else {
+        if (row < q.rows_out && col_s < q.m) ypanel[col_s * q.ldy + row] = v;
+      }
+    }
+    if constexpr (G::STRIP == 1) {
       const uint32_t row = rb_c * G::BM + G::BM + c;
       const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + g;
       double v[4];
@@ -1605,7 +1648,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
-      if constexpr (G::STRIP != 0) sacc = zero4;
+      if constexpr (G::STRIP != 0) { sacc = zero4; sacc1 = 0.0; }
     }
   };
   auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
@@ -1865,6 +1908,9 @@ using GeoWide32 = Geo<1, 4, 2, 4, 2>;
 // GeoTall + the strip: 272 x 128 per tile, 150 KiB ring — the last 256-row block of an operator of 256 a + r rows, r <= 16,
 // with those r rows riding along (+ 2 MFMAs per 32 and two fragment reads per k pair and wave): no second pass over the panel
 using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
+// GeoTall + the MINI strip (round 5): the last 256-row block of an operator of 256 a + r rows, r <= 4 — every N = 2^p + 1 grid has
+// r = 1 — with those rows riding on v_mfma_f64_4x4x4_4b_f64: + 4 x 17 instead of + 4 x 64 cycles per stage and wave
+using GeoTallMini = Geo<4, 2, 4, 4, 3, 2>;
 
 // BM 96 x BN 128, 4 waves side by side (96 x 32 each: six row tiles, two column tiles), two-slot ring (56 KiB, 2 WG per CU): operators
 // of 65-96 rows as ONE row block of their own height instead of a 128-row block that is a quarter to a half padding.  Plain and
@@ -1889,7 +1935,7 @@ using Geo224 = Geo<1, 4, 14, 1, 2>;
 // operators of 129-160 rows in ONE pass (before: 128 rows + a second launch at the copy rate; N = 160: 0.68 -> 0.77 of the peak)
 using Geo160 = Geo<1, 4, 10, 1, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9 };
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9, GEO_TALL_MINI = 10 };
 
 }  // namespace sri
 
@@ -1910,8 +1956,10 @@ static void pack_operator(const double* A, size_t lda, uint32_t rows, uint32_t k
           for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 2; ++e, ++o) {
               // (the strip's tile, if the geometry has one, follows the BM rows of its — only — row block: row slot = row)
+              // (the mini strip's tile holds rows BM .. BM + 3 in each of its four groups of four row slots: the 4x4x4 MFMA pairs column
+              //  block b with slots 4 b .. 4 b + 3)
               const uint32_t row = tile < G::BM / 16 ? rb * G::BM + (tile / G::TM) * (G::TM * 16) + row_of_slot(tile % G::TM, l & 15)
-                                                     : rb * G::BM + G::BM + static_cast<uint32_t>(l & 15);
+                                                     : rb * G::BM + G::BM + static_cast<uint32_t>(G::STRIP == 2 ? (l & 3) : (l & 15));
               const uint32_t k = kc * BK + k_of(asc, j, l >> 4, e);
               if (row < rows && k < kdim) out[o] = A[row + static_cast<size_t>(k) * lda];
               else if (w != nullptr && row < rows && k == kdim) out[o] = -w[row];

@@ -26,7 +26,7 @@ namespace sri {
 namespace plan {
 
 // ids as sri::GeoId (sri_apply_kernel.h)
-enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, G224 = 9, GEO_COUNT = 10 };
+enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, G224 = 9, TALL_MINI = 10, GEO_COUNT = 11 };
 
 // ---- rows: the operator's own geometry, and the parts it is cut into (sri_apply.hip's create_from_matrix) ----------------------
 // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry is
@@ -47,7 +47,7 @@ struct RowPart {
 // 256-row geometry plus a last part of 1-64 rows — as a 16-row strip of the last 256-row block if it is at most 16 rows
 // (then the first a - 1 blocks are a part of their own), else in the 32 x 256 / 64 x 256 geometry.  Returns the number of parts
 // (0: the operator stays whole).
-inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool extended = true) {
+inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool extended = true, bool allow_mini = true) {
   int np = 0;
   // the rows behind the last full 256-row block: 1 ... 256 of them (all of the operator's rows when it has at most 256)
   const uint32_t full = rows > 256 ? (rows - 1) / 256 * 256 : 0, rest = rows - full;
@@ -61,8 +61,9 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
     return np;
   }
   if (rest <= 16 && allow_strip) {
+    // (at most four rows — ONE on every N = 2^p + 1 grid — ride on the 4x4x4 MFMA: the mini strip, a quarter of the strip's cost)
     if (full > 256) out[np++] = RowPart{TALL, 0, full - 256, full / 256 - 1};
-    out[np++] = RowPart{TALL_STRIP, full - 256, 256 + rest, 1};
+    out[np++] = RowPart{(rest <= 4 && allow_mini) ? TALL_MINI : TALL_STRIP, full - 256, 256 + rest, 1};
   } else if (rest <= 64) {
     out[np++] = RowPart{TALL, 0, full, full / 256};
     out[np++] = RowPart{rest <= 32 ? WIDE32 : WIDE, full, rest, 1};
@@ -77,7 +78,7 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
 
 // rows of a tile of each geometry (the strip: 256 + 16)
 inline uint32_t tile_rows(int geo) {
-  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160, 224};
+  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160, 224, 272};
   return bm[geo];
 }
 
@@ -101,6 +102,7 @@ inline const GeoModel& model(int geo) {
       /* G192  192 x 64  */ {64, 2, {1.70, 3.20, 0, 0, 0}, 1.60, 0.0},     // (N = 192: 10.7 rounds in 408.5 us)
       /* G160  160 x 64  */ {64, 2, {1.50, 2.80, 0, 0, 0}, 1.40, 0.0},     // (N = 160: 12.8 rounds in 355.6 us)
       /* G224  224 x 64  */ {64, 2, {2.00, 3.75, 0, 0, 0}, 1.90, 0.0},     // (N = 224: 9.14 rounds in 480.7 us)
+      /* MINI  256+4 x 128 */ {128, 1, {4.15, 0, 0, 0, 0}, 4.15, 0.0},    // (the tall geometry + four 17-cycle MFMAs per stage and wave; N = 257: 8 rounds x 17 chunks in 565 us)
   };
   return table[geo];
 }

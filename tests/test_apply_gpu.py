@@ -76,6 +76,7 @@ def test_apply_matches_oracle(sri, oracle, n, which, M, kind, planned):
 WIDE_TALL = "256x128,dma>+<64x256"
 THIN_TALL = "256x128,dma>+<32x256"     # a last part of at most 32 rows
 STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256 a + r rows, r <= 16: the r rows ride with the last block
+MINI1, MININ = "f64<256+4x128,dma>", "<256x128,dma>+<256+4x128,dma>"         # ... r <= 4 (round 5): on the 4x4x4 MFMA
 
 
 @pytest.mark.parametrize("n,which,M,geometry", [
@@ -85,8 +86,12 @@ STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256
     (97, 2, 130, "<96x128,dma>"),    # Dn_NN of a 97-node grid: 96 rows
     (98, 0, 200, "<128x128,dma>"),
     (256, 0, 300, "<256x128,dma>"),  # a full 256-row block
-    (257, 0, 300, STRIP1),           # 257 ... 272 rows (round 4): ONE launch, the last 1-16 rows as a strip of the 256-row block
-    (258, 1, 515, STRIP1),           # 257 rows of an integration operator
+    (257, 0, 300, MINI1),            # 257 ... 260 rows (round 5): ONE launch, the last 1-4 rows as a mini strip of the 256-row block
+    (258, 1, 515, MINI1),            # 257 rows of an integration operator
+    (260, 0, 300, MINI1),            # four rows
+    (261, 2, 130, MINI1),            # Dn_NN of 261 nodes: 260 rows
+    (261, 0, 300, STRIP1),           # 261 ... 272 rows (round 4): the last 5-16 rows as a strip of the 256-row block
+    (266, 1, 515, STRIP1),           # 265 rows of an integration operator: k tail
     (272, 0, 130, STRIP1),
     (273, 0, 300, THIN_TALL),        # 273 ... 320 rows: 256 rows in the tall geometry + the last 17-64 as a part of their own:
     (288, 0, 515, THIN_TALL),        # ... 32 x 256 tiles up to 32 rows, 64 x 256 above
@@ -100,13 +105,13 @@ STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256
     (448, 1, 515, "<256x128,dma>+<192x64,dma>"),    # 447 rows
     (449, 0, 200, "<256x128,dma>"),  # the last 256-row block is three quarters full again
     (700, 0, 140, "<256x128,dma>+<192x64,dma>"),    # ascending k: two row blocks + 188 rows
-    (513, 0, 140, STRIPN),           # ascending k: one plain row block + the last block with its strip        # ascending-k builds of both parts, two row blocks + one row
+    (513, 0, 140, MININ),           # ascending k: one plain row block + the last block with its strip        # ascending-k builds of both parts, two row blocks + one row
     (560, 2, 150, WIDE_TALL),        # Dn_NN of a 560-node grid: 559 rows, ascending k with a k tail
     (640, 0, 140, "<128x128,dma>"),  # above 512 rows: the ascending-k build of the 128-row geometry (five row blocks)
     (641, 1, 90, "<128x128,dma>"),   # 640 rows, paired order (integration operator)
     (897, 0, 70, "<256x128,dma>+<160x64,dma>"),
     (960, 0, 70, "<256x128,dma>+<192x64,dma>"),
-    (1025, 0, 2100, STRIPN),         # three row blocks + the last with one more row
+    (1025, 0, 2100, MININ),         # three row blocks + the last with one more row
     (1040, 0, 300, STRIPN),          # ... with sixteen
     (1041, 0, 300, THIN_TALL),      # four row blocks (XCD-grouped walk of the main part) + one row
     (130, 0, 300, "<160x64,dma>"),   # 129 ... 160 rows (round 4): one 160-row block, 160 x 64 tiles (ten row tiles per wave)
@@ -234,7 +239,8 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
     import torch
 
     for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (200, 0, 1000, 1), (209, 1, 515, 0), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
-                                  (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3)]:
+                                  (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3),
+                                  (259, 1, 515, 2), (260, 0, 2049, 0), (516, 0, 300, 1), (1027, 2, 200, 0), (269, 0, 300, 0)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
         ops = []
@@ -255,7 +261,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64", "224x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "96x128", "192x64", "160x64", "224x64")), (outs[0][2], outs[1][2])
+        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or "256+4" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64", "224x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "256+4", "96x128", "192x64", "160x64", "224x64")), (outs[0][2], outs[1][2])
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
         assert torch.equal(outs[0][1], outs[0][0][:, 0])
         if which == 1:
@@ -324,7 +330,7 @@ def test_column_plan_gives_the_bits_of_the_own_geometry(sri):
     cases = [(256, 0, 40000, 0, ("<256x128,dma>|<64x64,dma>", FLAT)), (256, 1, 40000, 1, ("<256x128,dma,lean>|<64x64,dma>", FLAT)),
              (256, 1, 49152, 0, ("<256x128,dma,lean>|<128x128,dma>", FLAT)), (256, 0, 16384, 3, (MID,)), (256, 1, 3000, 0, (FLAT,)),
              (320, 0, 40000, 0, ("<256x128,dma>+<64x256,dma>|<64x64,dma>", FLAT)), (300, 1, 36001, 2, ("|<64x64,dma>", FLAT)),
-             (257, 0, 40000, 3, ("<256+16x128,dma>,lean|<64x64,dma>", FLAT)), (512, 0, 40000, 0, ("<256x128,dma>|<128x128,dma>", FLAT)),
+             (257, 0, 40000, 3, ("<256+4x128,dma>,lean|<64x64,dma>", FLAT)), (512, 0, 40000, 0, ("<256x128,dma>|<128x128,dma>", FLAT)),
              (1024, 0, 4096, 0, (MID,)), (1023, 2, 1000, 1, (MID,)), (128, 0, 16384, 0, (FLAT,)), (384, 0, 100000, 0, ("<128x128,dma>|<64x64,dma>", FLAT)),
              (1024, 0, 20000, 0, ("<256x128,dma>|<128x128,dma>",)), (1024, 2, 20000, 1, ("<256x128,dma,lean>|<128x128,dma>",)),
              (1050, 0, 20000, 0, ("dma",))]
