@@ -59,6 +59,13 @@ def test_one_rank_rccl_group_runs_the_multi_gpu_path():
         d = _run([sys.executable, "bench.py", "--gather", mode] + SMALL, env={"SRI_BENCH_FORCE_DIST": "1"})
         assert d["config"]["gather"] == mode and d["gathered_state_verified"] is True
         assert d["tip_state_allgather_ms"] > 0
+        # the multi-GPU code path carries everything the N = 1 line carries (round 5): a real SCALE record can be checked
+        # against a BENCH record key by key — roofline, the CPU baseline measured on rank 0, compute-only and gather figures
+        assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["measured_beside_ranks"] == 1
+        assert d["ms_per_step_compute_only"] > 0 and d["value_compute_only"] >= d["value"] and "final_gather_ms" in d
+        assert d["parity"]["north_star_tolerance_met"] is True
 
 
 def test_two_rank_rehearsal_under_torchrun():
