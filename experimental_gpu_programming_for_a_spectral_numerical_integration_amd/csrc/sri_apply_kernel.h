@@ -153,7 +153,9 @@ struct Geo {
   static constexpr int X_DMA_PER_WAVE = X_BYTES / 1024 / NW;
   static constexpr int DMA_PER_WAVE = A_DMA_PER_WAVE + X_DMA_PER_WAVE;   // vmcnt units per stage and wave
   static constexpr int AHEAD = NSTAGE - 1;                              // stages in flight beyond the one computed
-  static constexpr int NSTORE = TM * TN * 2 + (STRIP == 1 ? 4 : (STRIP == 2 ? 1 : 0));   // Y store instructions per wave of a full tile (the strip: four of 8 bytes; the mini strip: one)
+  // the mini strip's BN columns are dealt to the waves of a column group 16 at a time: TN / WM strip column tiles per wave (tall: 1, mid: 2)
+  static constexpr int SPW = STRIP == 2 ? (TN / WM > 0 ? TN / WM : 1) : 1;
+  static constexpr int NSTORE = TM * TN * 2 + (STRIP == 1 ? 4 : (STRIP == 2 ? SPW : 0));   // Y store instructions per wave of a full tile (the strip: four of 8 bytes; the mini strip: one per strip column tile)
   // EPI_QUAT: the strain coefficients of a tile's rods (BN/4 rods x 9 doubles, contiguous in memory) travel with the
   // tile's first stage into a side buffer behind the ring; QE_BUFS tiles may be between "issued" and "epilogue read".
   // Each buffer also holds the Legendre factor P1 of the tile's BM rows.  Two buffers are enough when a tile has
@@ -185,7 +187,8 @@ struct Geo {
   // (an operator slab that does not split evenly over the waves — the strip's 34 pieces, a 96-row block's 12 over eight waves —
   // has its last pieces fetched twice: same bytes, same place)
   static_assert(A_BYTES % 1024 == 0 && X_BYTES % (1024 * NW) == 0, "stage must split into whole 1-KiB DMA pieces per wave");
-  static_assert(STRIP == 0 || (WM == TN && TM % 2 == 0), "the strip's BN columns are dealt 16 per wave: wave (wm, wn) takes column tile wm of its own 16 TN");
+  static_assert(STRIP == 0 || (TM % 2 == 0 && (STRIP == 2 ? TN % WM == 0 : WM == TN)),
+                "the strip's BN columns are dealt 16 per wave: wave (wm, wn) takes column tile wm of its own TN (the mini strip: tiles wm TN / WM ... of them)");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds a CU");
   static_assert(TM % 2 == 0, "rows of vertically adjacent tile pairs are interleaved (sri_internal.h)");
   static_assert((AHEAD - 1) * DMA_PER_WAVE + NSTORE <= 63, "counted vmcnt must fit the 6-bit counter");
@@ -849,10 +852,16 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // wave's own TN column tiles — and ONE set of fragments for it, read at the top of a k pair (behind the pair's own
   // fragments, which are in registers by then) and consumed after the last MFMA group of each k-step: 16 registers in all.
   d4 sacc = d4{0.0, 0.0, 0.0, 0.0};
-  double sacc1 = 0.0;                                          // STRIP == 2: D[column 4 (c >> 2) + g of the wave's strip tile][row BM + (c & 3)]
+  constexpr int SPW = G::SPW;
+  double sacc1[SPW];                                           // STRIP == 2: D[column 4 (c >> 2) + g of the wave's strip tile i][row BM + (c & 3)]
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) sacc1[i] = 0.0;
   d2 sfa = d2{0.0, 0.0}, sfb = d2{0.0, 0.0};
+  d2 sfbm[SPW];                                                // the mini strip's X fragments: one per strip column tile of the wave
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) sfbm[i] = d2{0.0, 0.0};
   const int s_a_off = G::A_STRIP_OFFSET + lane * 16;
-  const int s_x_add = wm * 16 * X_ROW_BYTES;                    // from the wave's column tile 0 to its column tile wm
+  const int s_x_add = wm * SPW * 16 * X_ROW_BYTES;              // from the wave's column tile 0 to its (first) strip column tile
   // One stage: 2 k pairs x (TM + TN fragment reads, 2*TM*TN MFMAs).
   // Half-stage primitives.  A stage is 2 k pairs; a k pair is TM+TN fragment reads and 2*TM MFMA
   // "groups" (k-step e, row tile tm) of TN MFMAs each.  With PIECES (steady state of the DMA build) one
@@ -895,7 +904,20 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     if constexpr (G::STRIP != 0) {
       const char* base = smem + slot * G::STAGE_BYTES;
       sfa = *reinterpret_cast<const d2*>(base + s_a_off + j * 1024);
-      if constexpr (ASCK) {
+      if constexpr (G::STRIP == 2) {
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+          if constexpr (ASCK) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              sfbm[i][e] = *reinterpret_cast<const double*>(base + xq[ASCK ? j : 0][e] + s_x_add + i * 16 * X_ROW_BYTES);
+              asm volatile("" ::: "memory");
+            }
+          } else {
+            sfbm[i] = *reinterpret_cast<const d2*>(base + xpp[j] + s_x_add + i * 16 * X_ROW_BYTES);
+          }
+        }
+      } else if constexpr (ASCK) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           sfb[e] = *reinterpret_cast<const double*>(base + xq[ASCK ? j : 0][e] + s_x_add);
@@ -925,7 +947,10 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         // [l >> 4][l & 15]) but only multiplies inside the four 4 x 4 diagonal blocks — lane (c, g) receives D[4 (c >> 2) + g][c]:
         // column 4 (c >> 2) + g against row SLOT c, which the host packs with operator row BM + (c & 3).  The same chain of four
         // fused multiply-adds over the k slots (measured bit for bit: tools/mfma_f64_4x4_probe.hip).
-        if (tm == TM - 1) sacc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sfb[e], sfa[e], sacc1, 0, 0, 0);
+        if (tm == TM - 1) {
+#pragma unroll
+          for (int i = 0; i < SPW; ++i) sacc1[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(sfbm[i][e], sfa[e], sacc1[i], 0, 0, 0);
+        }
       }
       if constexpr (PIECES) {
         if (piece < G::DMA_PER_WAVE) {
@@ -1240,35 +1265,39 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // `staged` (R1X epilogue): the rank-1 operands of this tile are in LDS (r1_side, buffer of the finished tile's parity)
   auto store_strip = [&](const ApplyArgs& q, uint32_t rb_c, size_t col0_c, double* ypanel, bool counted, const char* staged = nullptr) __attribute__((always_inline)) {
     if constexpr (G::STRIP == 2) {
-      // lane (c, g): row BM + (c & 3), column 4 (c >> 2) + g of the wave's strip column tile — ONE 8-byte store per lane; on the
-      // counted path it is issued by every wave whatever the number of valid rows (exec mask), like the strip's four
+      // lane (c, g): row BM + (c & 3), column 4 (c >> 2) + g of each of the wave's SPW strip column tiles — ONE 8-byte store per lane
+      // and tile; on the counted path every wave issues them whatever the number of valid rows (exec mask), like the strip's four
       const uint32_t row = rb_c * G::BM + G::BM + (c & 3);
-      const size_t col_s = col0_c + wn * (TN * 16) + wm * 16 + 4 * (c >> 2) + g;
-      double v = sacc1;
-      if constexpr (RANK1_EPI) {
-        if (staged != nullptr) {
-          const double ws = *reinterpret_cast<const double*>(staged + G::R1_XB_BYTES + (G::BM + (c & 3)) * 8);
-          const double xs = *reinterpret_cast<const double*>(staged + (wn * (TN * 16) + wm * 16 + 4 * (c >> 2) + g) * 8);
-          v = __builtin_fma(-ws, xs, v);
-        } else if (row < q.rows_out && col_s < q.m) {
-          v = __builtin_fma(-q.w[row], q.xb[col_s], v);
+#pragma unroll
+      for (int i = 0; i < SPW; ++i) {
+        const int ctile = wn * (TN * 16) + (wm * SPW + i) * 16;      // the strip column tile's first column inside the tile
+        const size_t col_s = col0_c + ctile + 4 * (c >> 2) + g;
+        double v = sacc1[i];
+        if constexpr (RANK1_EPI) {
+          if (staged != nullptr) {
+            const double ws = *reinterpret_cast<const double*>(staged + G::R1_XB_BYTES + (G::BM + (c & 3)) * 8);
+            const double xs = *reinterpret_cast<const double*>(staged + (ctile + 4 * (c >> 2) + g) * 8);
+            v = __builtin_fma(-ws, xs, v);
+          } else if (row < q.rows_out && col_s < q.m) {
+            v = __builtin_fma(-q.w[row], q.xb[col_s], v);
+          }
         }
-      }
-      if (counted) {
+        if (counted) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t valid = q.rows_out - (rb_c * G::BM + G::BM);                    // 1 .. 4 rows of the mini strip exist
-        const uint32_t m4 = valid >= 4u ? 0xfu : ((1u << valid) - 1u);
-        const unsigned long long mask = 0x1111111111111111ull * m4;                    // row (c & 3) < valid, in every group of four lanes
-        const size_t ldy8 = q.ldy * sizeof(double);
-        char* const b0 = reinterpret_cast<char*>(ypanel) + (col0_c + wn * (TN * 16) + wm * 16) * ldy8 + (static_cast<size_t>(rb_c) * G::BM + G::BM) * sizeof(double);
-        const uint32_t off = (4u * (static_cast<uint32_t>(c) >> 2) + static_cast<uint32_t>(g)) * static_cast<uint32_t>(ldy8) + (static_cast<uint32_t>(c) & 3u) * 8u;
-        asm volatile("s_mov_b64 exec, %3\n\t"
-                     "global_store_dwordx2 %0, %1, %2\n\t"
-                     "s_mov_b64 exec, -1\n\ts_nop 1"
-                     ::"v"(off), "v"(v), "s"(b0), "s"(mask) : "memory");
+          const uint32_t valid = q.rows_out - (rb_c * G::BM + G::BM);                    // 1 .. 4 rows of the mini strip exist
+          const uint32_t m4 = valid >= 4u ? 0xfu : ((1u << valid) - 1u);
+          const unsigned long long mask = 0x1111111111111111ull * m4;                    // row (c & 3) < valid, in every group of four lanes
+          const size_t ldy8 = q.ldy * sizeof(double);
+          char* const b0 = reinterpret_cast<char*>(ypanel) + (col0_c + ctile) * ldy8 + (static_cast<size_t>(rb_c) * G::BM + G::BM) * sizeof(double);
+          const uint32_t off = (4u * (static_cast<uint32_t>(c) >> 2) + static_cast<uint32_t>(g)) * static_cast<uint32_t>(ldy8) + (static_cast<uint32_t>(c) & 3u) * 8u;
+          asm volatile("s_mov_b64 exec, %3\n\t"
+                       "global_store_dwordx2 %0, %1, %2\n\t"
+                       "s_mov_b64 exec, -1\n\ts_nop 1"
+                       ::"v"(off), "v"(v), "s"(b0), "s"(mask) : "memory");
 #endif
-      } else {
-        if (row < q.rows_out && col_s < q.m) ypanel[col_s * q.ldy + row] = v;
+        } else {
+          if (row < q.rows_out && col_s < q.m) ypanel[col_s * q.ldy + row] = v;
+        }
       }
     }
     if constexpr (G::STRIP == 1) {
@@ -1648,7 +1677,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = zero4;
-      if constexpr (G::STRIP != 0) { sacc = zero4; sacc1 = 0.0; }
+      if constexpr (G::STRIP != 0) {
+        sacc = zero4;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) sacc1[i] = 0.0;
+      }
     }
   };
   auto advance_compute = [&]() __attribute__((always_inline)) -> bool {   // true if the stage just left was a tile's last
@@ -1911,6 +1944,9 @@ using GeoTallStrip = Geo<4, 2, 4, 4, 3, 1>;
 // GeoTall + the MINI strip (round 5): the last 256-row block of an operator of 256 a + r rows, r <= 4 — every N = 2^p + 1 grid has
 // r = 1 — with those rows riding on v_mfma_f64_4x4x4_4b_f64: + 4 x 17 instead of + 4 x 64 cycles per stage and wave
 using GeoTallMini = Geo<4, 2, 4, 4, 3, 2>;
+// GeoMid + the mini strip: 129 ... 132 rows — N = 129, the 2^p + 1 grid of this size — as ONE 128-row block with its 1-4 leftover rows
+// on the 4x4x4 MFMA, two strip column tiles per wave (before: a 160-row block that is 81 % full)
+using GeoMidMini = Geo<2, 2, 4, 4, 2, 2>;
 
 // BM 96 x BN 128, 4 waves side by side (96 x 32 each: six row tiles, two column tiles), two-slot ring (56 KiB, 2 WG per CU): operators
 // of 65-96 rows as ONE row block of their own height instead of a 128-row block that is a quarter to a half padding.  Plain and
@@ -1935,7 +1971,7 @@ using Geo224 = Geo<1, 4, 14, 1, 2>;
 // operators of 129-160 rows in ONE pass (before: 128 rows + a second launch at the copy rate; N = 160: 0.68 -> 0.77 of the peak)
 using Geo160 = Geo<1, 4, 10, 1, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9, GEO_TALL_MINI = 10 };
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9, GEO_TALL_MINI = 10, GEO_MID_MINI = 11 };
 
 }  // namespace sri
 

@@ -71,4 +71,15 @@ void pack_mini(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32
   pack_operator<GeoTallMini>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
 }
 
+// the 128-row geometry with the mini strip (GeoMidMini: 129 ... 132 rows)
+int prepare_midmini(int dev) { return prepare_strip_geometry<GeoMidMini>(dev); }
+int resident_midmini(int dev) { return (dev < 0 || dev >= kMaxDevices) ? 0 : residency<GeoMidMini, true, false, true>(dev).load(std::memory_order_acquire); }
+int dispatch_midmini(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean) {
+  return dispatch_strip_geometry<GeoMidMini>(h, args, rank1, stream, lean);
+}
+void pack_midmini(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+                  std::vector<double>& out) {
+  pack_operator<GeoMidMini>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
+
 }  // namespace sri
