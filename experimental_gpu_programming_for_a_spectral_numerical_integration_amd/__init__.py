@@ -22,7 +22,7 @@ __all__ = [
     "ComputeChebyshevPoints", "GetCoefficients_c", "getDn", "dn_blocks", "integration_matrix", "ivp",
     "SpectralApply", "RodIntegrator", "OP_DN", "OP_DNN_INV", "OP_DNN",
     "OPT_COLUMN_PLAN", "OPT_LEAN_TAIL", "OPT_ROW_PARTS", "OPT_SMALL_KERNEL", "OPT_XCD_TILE_WALK", "OPT_HOST_COPY_THREADS",
-    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION", "ROD_OPT_FIRST_SWEEP_CHECK", "ROD_OPT_FUSED_POSITION_RHS",
+    "OPT_HOST_BLOCK_COLUMNS", "OPT_MAX_WORKGROUPS", "OPT_PLAN_CALIBRATION", "ROD_OPT_FIRST_SWEEP_CHECK", "ROD_OPT_FUSED_POSITION_RHS", "ROD_OPT_FUSED_CRITERION",
 ]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +33,7 @@ OP_DN, OP_DNN_INV, OP_DNN = 0, 1, 2
 # sri_option (include/sri_capi.h)
 (OPT_COLUMN_PLAN, OPT_LEAN_TAIL, OPT_ROW_PARTS, OPT_SMALL_KERNEL, OPT_XCD_TILE_WALK, OPT_HOST_COPY_THREADS, OPT_HOST_BLOCK_COLUMNS,
  OPT_MAX_WORKGROUPS, OPT_PLAN_CALIBRATION) = range(1, 10)
-ROD_OPT_FIRST_SWEEP_CHECK, ROD_OPT_FUSED_POSITION_RHS = 100, 101   # sri_rod_set_option only
+ROD_OPT_FIRST_SWEEP_CHECK, ROD_OPT_FUSED_POSITION_RHS, ROD_OPT_FUSED_CRITERION = 100, 101, 102   # sri_rod_set_option only
 
 _dp = C.POINTER(C.c_double)
 _lib: Optional[C.CDLL] = None
@@ -68,6 +68,7 @@ C_ABI = {
     "sri_apply_set_option": (_int, [_vp, _int, C.c_long]),
     "sri_apply_get_option": (_int, [_vp, _int, C.POINTER(C.c_long)]),
     "sri_rod_set_option": (_int, [_vp, _int, C.c_long]),
+    "sri_rod_get_option": (_int, [_vp, _int, C.POINTER(C.c_long)]),
     "sri_apply_destroy": (_int, [_vp]),
     "sri_rod_create": (_int, [C.POINTER(_vp), _u32, _int]),
     "sri_rod_destroy": (_int, [_vp]),
@@ -484,6 +485,12 @@ class RodIntegrator:
     def set_option(self, option: int, value: int) -> None:
         """``sri_rod_set_option``: an ``OPT_*`` switch on every apply handle inside this rod handle."""
         _chk(load_library().sri_rod_set_option(self._h, int(option), int(value)), "sri_rod_set_option")
+
+    def get_option(self, option):
+        """``sri_rod_get_option``."""
+        v = C.c_long(0)
+        _chk(load_library().sri_rod_get_option(self._h, int(option), C.byref(v)), "sri_rod_get_option")
+        return int(v.value)
 
     @property
     def last_apply_kernel(self) -> str:

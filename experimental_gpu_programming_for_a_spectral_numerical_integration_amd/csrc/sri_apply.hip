@@ -19,10 +19,11 @@ static_assert(plan::FLAT == GEO_FLAT && plan::MID == GEO_MID && plan::TALL == GE
 static thread_local int g_last_hip_error = 0;
 void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 
-static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean = false, bool qb = false) {
-  // (the closing product of a rod solve, EPI_QB: Q and the position right-hand side from one launch — 128- and 256-row geometries)
-  static const char* qb_names[2] = {"sri_apply_mfma_f64<256x128,dma,q+b>", "sri_apply_mfma_f64<256x128,dma,q+b,lean>"};
-  if (qb && geo == GEO_TALL) return qb_names[lean ? 1 : 0];
+static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean = false, bool qb = false, bool crit = false) {
+  // (the closing product of a rod solve, EPI_QB: Q and the position right-hand side from one launch; EPI_QBC: and the criterion — 256-row geometry)
+  static const char* qb_names[4] = {"sri_apply_mfma_f64<256x128,dma,q+b>", "sri_apply_mfma_f64<256x128,dma,q+b,lean>",
+                                    "sri_apply_mfma_f64<256x128,dma,q+b+criterion>", "sri_apply_mfma_f64<256x128,dma,q+b+criterion,lean>"};
+  if (qb && geo == GEO_TALL) return qb_names[(lean ? 1 : 0) + (crit ? 2 : 0)];
   static const char* names[3][4] = {
       {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<64x64,reg,quat>",
        "sri_apply_mfma_f64<64x64,dma,quat>"},
@@ -288,6 +289,7 @@ struct ManyPanels {
 struct PositionOut {         // integrate_with_position_rhs: the second panel of an EPI_QB launch
   double* b;
   size_t ld;
+  const FixedPointCriterion* crit = nullptr;   // ... and, with it, EPI_QBC
 };
 
 static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t ldy, size_t M, const double* d_xb,
@@ -302,6 +304,12 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     //  N = 128, and 257 ... 384 rows — three more stores per rod and row pair at every tile end cost what the lighter pass saves:
     //  profiles/r05_rod_ab_closing_product.log)
     if (h->rows % 16 == 0 || h->rows < 16 || h->geo != GEO_TALL || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
+    if (pos->crit != nullptr) {
+      const FixedPointCriterion& cr = *pos->crit;
+      if (cr.qe == nullptr || cr.leg1 == nullptr || cr.words == nullptr) return SRI_EINVAL;
+      // (the criterion re-reads X as the accumulators sit: 16-byte pairs of rows, the last of which may reach one row past an odd row count)
+      if (ldx % 2 != 0 || reinterpret_cast<uintptr_t>(dX) % 16 != 0 || ldx < h->rows + (h->rows & 1u) || h->nk < 3 || h->row_blocks > 2) return SRI_EUNSUPPORTED;
+    }
   }
   if (many == nullptr && M > 0 && (dX == nullptr || dY == nullptr)) return SRI_EINVAL;
   if (many != nullptr && (many->xs == nullptr || many->ys == nullptr || d_xb != nullptr || d_tips != nullptr || quat != nullptr)) return SRI_EINVAL;
@@ -327,8 +335,12 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   args.w = h->d_w;
   args.xb = d_xb;
   args.tips = d_tips;
-  args.qe = quat ? quat->qe : nullptr;
-  args.leg1 = quat ? quat->leg1 : nullptr;
+  const FixedPointCriterion* const crit = pos ? pos->crit : nullptr;
+  args.qe = quat ? quat->qe : (crit ? crit->qe : nullptr);
+  args.leg1 = quat ? quat->leg1 : (crit ? crit->leg1 : nullptr);
+  args.crit = crit ? crit->words : nullptr;
+  args.crit_clear = crit ? crit->clear : nullptr;
+  args.crit_words = crit ? kCriterionWords : 0u;
   args.side_bufs = 0;   // set by launch()
   args.tips_prev = quat ? quat->tips_prev : nullptr;
   args.partial = quat ? quat->partial : nullptr;
@@ -456,7 +468,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     if (ch.alt < 0) {
       const bool lean = lean_for(0, M);
       h->last_kernel.store(in_parts ? (lean ? h->parts_name_lean : h->parts_name)
-                                    : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3), pos != nullptr), std::memory_order_relaxed);
+                                    : kernel_name(h->geo, dma, quat != nullptr, lean && (quat == nullptr || args.nk >= 3), pos != nullptr, crit != nullptr), std::memory_order_relaxed);
       return primary(many == nullptr ? columns(0, M) : args, lean);
     }
     const sri_apply_handle::Alternate& alt = h->alternates[ch.alt];
@@ -530,9 +542,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
 }
 
 int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, double* dQ, size_t ldq, double* dB,
-                                size_t ldb, size_t M, void* stream) {
+                                size_t ldb, size_t M, void* stream, const FixedPointCriterion* crit) {
   if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
-  const PositionOut pos{dB, ldb};
+  const PositionOut pos{dB, ldb, crit};
   return run(h, dG, ldg, dQ, ldq, M, d_x_base, static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, nullptr, &pos);
 }
 

@@ -233,6 +233,13 @@ struct ApplyArgs {
   uint32_t nt_stores;    // 1: every column of Y starts on a 128-byte line -> non-temporal stores (plain epilogue only)
   double* y2;            // EPI_QB only: the position right-hand side b = R(q) e1 (main.cpp:121-140), 3 columns per rod, m/4 rods
   size_t ldy2;           //   leading dimension of that panel; > rows_out when rows_out is odd (the last row pair is stored whole)
+  // EPI_QBC only (the criterion of a rod solve from the closing product's accumulators): crit[0] = bits of max |d| over the panel,
+  // crit[1 + rb * WM + wm] = bits of the largest sum of d^2 over the 16 TM rows of wave row wm of row block rb that any COLUMN has,
+  // d = 1/2 A(K) Q - X (accumulated with atomic max: the caller hands over zeroed words); workgroup 0 zeroes crit_clear[0 .. crit_words)
+  // — the words of the caller's NEXT launch — on its way in
+  unsigned long long* crit;
+  unsigned long long* crit_clear;
+  uint32_t crit_words;
   unsigned long long* stamps;   // diagnostic builds only (tools/apply_diag.hip): 8 words per workgroup
 };
 
@@ -293,6 +300,28 @@ __device__ __forceinline__ void store8_sv(char* uniform_base, uint32_t lane_offs
 #endif
 }
 
+// The same store / the matching load as the COMPILER issues them (global address space, uniform base + 32-bit lane offset + constant:
+// the instruction selector picks the saddr form).  EPI_QBC's epilogue mixes stores with loads whose values it consumes: with both
+// kinds visible to the compiler its own `s_waitcnt vmcnt(n)` count exactly what is younger — with the stores hidden in asm every wait
+// for a load would drain the stores issued after it.  (8-byte aligned: the shifted last pair of an odd row count.)
+typedef double d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <int OFFSET>
+__device__ __forceinline__ void store16_visible(char* uniform_base, uint32_t lane_offset, d2 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(lane_offset));   // (keeps the 32 -> 64-bit extension next to its use: hoisted out of the block, the selector no longer sees it and falls back to 64-bit lane addresses)
+#endif
+  auto* gp = (__attribute__((address_space(1))) char*)uniform_base;
+  *reinterpret_cast<__attribute__((address_space(1))) d2_a8*>(gp + static_cast<size_t>(lane_offset) + OFFSET) = v;
+}
+template <int OFFSET>
+__device__ __forceinline__ d2 load16_visible(const char* uniform_base, uint32_t lane_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(lane_offset));
+#endif
+  auto* gp = (const __attribute__((address_space(1))) char*)uniform_base;
+  return *reinterpret_cast<const __attribute__((address_space(1))) d2_a8*>(gp + static_cast<size_t>(lane_offset) + OFFSET);
+}
+
 // The two doubles of a 16-byte Y store come from two different accumulators and have to be copied side by side:
 // two 64-bit moves instead of the four 32-bit ones hipcc emits for the tuple (every VALU instruction costs MFMA time).
 __device__ __forceinline__ d2 pack2(double lo, double hi) {
@@ -319,6 +348,20 @@ __device__ __forceinline__ double row_above(double wrap, double hi) {
   return __builtin_bit_cast(double, (static_cast<long long>(up) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
 #else
   return wrap + hi;
+#endif
+}
+
+// A double from another lane of the same row of 16 by a DPP move per 32-bit half (no LDS crossbar, no lgkmcnt wait).  CTRL: 0x140
+// row_mirror (lane i <-> 15 - i), 0x141 row_half_mirror (i <-> 7 - i within each half), 0x4E / 0xB1 quad_perm (i <-> i ^ 2 / i ^ 1).
+template <int CTRL>
+__device__ __forceinline__ double dpp_exchange(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<long long>(static_cast<unsigned int>(lo)));
+#else
+  return v;
 #endif
 }
 
@@ -426,7 +469,15 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           position right-hand side b = R(q) e1 of main.cpp:121-140 (3 columns per rod, panel y2) — so that the confirmation
 //           pass behind it only READS.  Odd-row-count integration operators on the LDS-DMA path (DMA && RANK1 && TAIL: the
 //           rank-1 term is folded into the product, the accumulators ARE Q); no tips, no monitor.
-enum { EPI_NONE = 0, EPI_QUAT = 1, EPI_QB = 2 };
+//           EPI_QBC (round 5) = EPI_QB + the criterion of the fixed point: with Q in the accumulators, the NEXT right-hand side
+//           G' = 1/2 A(K) Q is formed in registers as EPI_QUAT does (strain coefficients and Legendre factors through the same side
+//           buffers) and compared with the right-hand side the product was formed from — the X panel itself, re-read in the accumulator
+//           layout — so that max |G' - X| and the column sums of (G' - X)^2 over each wave's 64 rows leave the launch in a few words:
+//           what confirm_fixed_point_kernel (sri_rod.hip) reads 8 doubles per rod and node for.
+enum { EPI_NONE = 0, EPI_QUAT = 1, EPI_QB = 2, EPI_QBC = 3 };
+#ifndef SRI_QBC_DEPTH
+#define SRI_QBC_DEPTH 2              // EPI_QBC: row pairs of X in flight ahead of the one whose criterion is being formed (A/B knob)
+#endif
 
 template <class G, bool DMA, bool RANK1, bool TAIL, bool STAMP = false, int ABL = 0, int EPI = EPI_NONE, bool ASC = false, bool LEAN = false>
 __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(const ApplyArgs p) {
@@ -435,8 +486,11 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   static_assert(!STAMP && ABL == 0, "stamped / ablated instantiations are diagnostic scaffolding: build with -DSRI_DIAG (tools/apply_diag.hip)");
 #endif
   static_assert(EPI == EPI_NONE || RANK1, "the quaternion epilogue includes the initial-value term");
-  static_assert(EPI != EPI_QB || (DMA && TAIL && G::STRIP == 0), "EPI_QB: odd-row-count operators on the LDS-DMA path (the rank-1 term rides in the product)");
-  static_assert(EPI != EPI_QUAT || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
+  constexpr bool QB = EPI == EPI_QB || EPI == EPI_QBC;          // Q and b = R(q) e1 leave the launch
+  constexpr bool CRIT = EPI == EPI_QBC;                         // ... and the criterion of the fixed point
+  constexpr bool QSIDE = EPI == EPI_QUAT || EPI == EPI_QBC;     // strain coefficients and Legendre factors of a tile travel through the side buffers
+  static_assert(!QB || (DMA && TAIL && G::STRIP == 0), "EPI_QB: odd-row-count operators on the LDS-DMA path (the rank-1 term rides in the product)");
+  static_assert(!QSIDE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
   // as operator column k = rows, and the X image gets xb[col] in that slot.  No epilogue arithmetic, no dependent loads.
@@ -613,7 +667,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // (i+1, 0), before barrier (i+1, 1).  With nk >= 3 chunks per tile, (j, 0) - 2 >= (j-1, 1): two buffers suffice;
   // with nk = 2 three, with nk = 1 (issue of tile j and epilogue of tile j-3 share a body) four.
   auto issue_qe = [&]() __attribute__((always_inline)) {
-    if constexpr (EPI == EPI_QUAT) {
+    if constexpr (QSIDE) {
       if (kc_i == 0) {
         const ApplyArgs q = SRI_ARGS_HERE;
         // 4-byte pieces (256 B per wave instruction): the caller's array ends exactly after the last rod, and a
@@ -652,7 +706,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   // (entry j = lane >> 1 is the column of lane j of tail_fix_fast()), into this wave's corner of the side buffer of tile
   // sequence parity.  In FRONT of the stage's own pieces, like the coefficient pieces of EPI_QUAT: the counted waits then
   // at worst wait for it too.  Read back by the SAME wave after its own vmcnt wait for the tile's last stage.
-  char* const xb_side = smem + (EPI == EPI_QUAT ? G::lds_bytes_quat(static_cast<int>(p.side_bufs)) : G::LDS_BYTES);
+  char* const xb_side = smem + (QSIDE ? G::lds_bytes_quat(static_cast<int>(p.side_bufs)) : G::LDS_BYTES);
   auto issue_xb = [&]() __attribute__((always_inline)) {
     if constexpr (XBUF) {
       if (kc_i == 0) {
@@ -815,9 +869,17 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   asm volatile("" : "+v"(ylane_q));
   // ... and of EPI_QB's second panel: rod g of the group is 3g columns in
   [[maybe_unused]] uint32_t ylane_b = 0;
-  if constexpr (EPI == EPI_QB) {
+  if constexpr (QB) {
     ylane_b = 3u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldy2 * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
     asm volatile("" : "+v"(ylane_b));
+  }
+  // ... and of EPI_QBC's reads of the X panel in the accumulator layout (the Q stores' pattern on the X panel's leading dimension)
+  [[maybe_unused]] uint32_t xlane_q = 0;
+  [[maybe_unused]] double crit_dmax = 0.0, crit_seg0 = 0.0, crit_seg1 = 0.0;   // EPI_QBC: this lane's running maxima (NaN sticks)
+  if constexpr (CRIT) {
+    xlane_q = 4u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldx * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
+    asm volatile("" : "+v"(xlane_q));
+    if (blockIdx.x == 0 && p.crit_clear != nullptr && static_cast<uint32_t>(tid) < p.crit_words) p.crit_clear[tid] = 0ull;
   }
   // fragment read addresses (bytes, relative to the slot base)
   const int a_off = wm * (TM * KPAIRS * 1024) + lane * 16;
@@ -1183,55 +1245,142 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       b[1] = txy + twz;
       b[2] = txz - twy;
     };
+    // EPI_QBC: d = 1/2 A(K) q - x at one node of one rod — K and the product in the operation order of strain_kernel /
+    // quat_rhs_kernel (sri_rod.hip: the bits of confirm_fixed_point_kernel's d) — into this lane's running max |d| and the four column sums
+    [[maybe_unused]] auto legendre2 = [](double P1) __attribute__((always_inline)) { return ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1); };   // as strain_kernel (sri_rod.hip)
+    [[maybe_unused]] const char* side = nullptr;
+    // (P1 of a row pair is read from the side buffer where it is used, pair by pair: 16 registers less across the epilogue)
+    [[maybe_unused]] auto legendre1 = [&](int t) __attribute__((always_inline)) {
+      return *reinterpret_cast<const d2*>(side + G::QE_BYTES + (wm * (TM * 16) + 2 * c + 32 * t) * 8);
+    };
+    if constexpr (CRIT) side = smem + G::LDS_BYTES + (tseq_c % q.side_bufs) * G::SIDE_BYTES;
+    [[maybe_unused]] auto criterion = [&](const double (&q9h)[9], double P1, double P2, const d4& qv, const double (&x4)[4], bool exists, double (&ss)[4])
+                                          __attribute__((always_inline)) {
+      double hk[3], gq[4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double sacc = q9h[a * 3 + 0];                          // P0 = 1; the coefficients are halved already (exact)
+        sacc = sacc + P1 * q9h[a * 3 + 1];
+        sacc = sacc + P2 * q9h[a * 3 + 2];
+        hk[a] = sacc;
+      }
+      quat_rhs_half(hk[0], hk[1], hk[2], qv[0], qv[1], qv[2], qv[3], gq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double diff = exists ? gq[r] - x4[r] : 0.0;
+        crit_dmax = __builtin_fmax(crit_dmax, fabs(diff));       // (one instruction; a NaN is dropped here and kept by the sum below)
+        ss[r] = __builtin_fma(diff, diff, ss[r]);
+      }
+    };
+    // the four column sums of a rod group, each over this lane's rows -> over the wave's 16 TM rows (the 16 lanes of equal g), and
+    // into the running maximum of the tile's row block: lanes c and 15 - c split the four columns between them (the lower half of the
+    // row keeps columns 0, 1), then c and 7 - c (23 - c) the two (the lower quad of a half keeps the first); the four lanes of a quad
+    // then hold four disjoint quarters of ONE column — quad k column k — which two exchanges inside the quad add up.  DPP moves only.
+    [[maybe_unused]] auto fold_columns = [&](const double (&ss)[4]) __attribute__((always_inline)) {
+      const bool hi8 = (c & 8) != 0, hi4 = (c & 4) != 0;
+      const double a0 = (hi8 ? ss[2] : ss[0]) + dpp_exchange<0x140>(hi8 ? ss[0] : ss[2]);
+      const double a1 = (hi8 ? ss[3] : ss[1]) + dpp_exchange<0x140>(hi8 ? ss[1] : ss[3]);
+      double bsum = (hi4 ? a1 : a0) + dpp_exchange<0x141>(hi4 ? a0 : a1);
+      bsum += dpp_exchange<0x4E>(bsum);
+      bsum += dpp_exchange<0xB1>(bsum);
+      const double n0 = (bsum > crit_seg0 || bsum != bsum) ? bsum : crit_seg0;
+      const double n1 = (bsum > crit_seg1 || bsum != bsum) ? bsum : crit_seg1;
+      crit_seg0 = rb_c == 0 ? n0 : crit_seg0;
+      crit_seg1 = rb_c == 0 ? crit_seg1 : n1;
+    };
     if constexpr (SRI_STORE_SADDR != 0) {
       if ((col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + 1)) {
         const bool odd = rb_c * G::BM + (wm + 1) * (TM * 16) == q.rows_out + 1;   // wave-uniform: this wave's last row does not exist
         const size_t ldy8 = q.ldy * sizeof(double), ldb8 = q.ldy2 * sizeof(double);
+        [[maybe_unused]] const size_t ldx8 = q.ldx * sizeof(double);
         const size_t row_off = (static_cast<size_t>(rb_c) * G::BM + wm * (TM * 16)) * sizeof(double);
         char* const ybase = reinterpret_cast<char*>(q.y) + (col0_c + wn * (TN * 16)) * ldy8 + row_off;
         char* const bbase = reinterpret_cast<char*>(q.y2) + ((col0_c + wn * (TN * 16)) / 4 * 3) * ldb8 + row_off;
+        [[maybe_unused]] const char* const xbase_c = reinterpret_cast<const char*>(q.x) + (col0_c + wn * (TN * 16)) * ldx8 + row_off;
         auto emit = [&](auto odd_tag) __attribute__((always_inline)) {
           constexpr bool ODD = decltype(odd_tag)::value;
+          constexpr int PAIRS = TM / 2, NP = TN * PAIRS;          // (rod group tn, row pair t) = pair number tn * PAIRS + t
+          constexpr int DEPTH = SRI_QBC_DEPTH < 1 ? 1 : (SRI_QBC_DEPTH > NP ? NP : SRI_QBC_DEPTH);
           char* ct = ybase;                                      // first Q column of rod group tn (uniform)
           char* bt = bbase;                                      // first b column of it
+          // EPI_QBC: the X panel where this lane's accumulators sit — 16 bytes per (pair, column), DEPTH pairs ahead of their use (plain
+          // loads: the compiler's own waits; they are all consumed inside this epilogue, so the stage stream's counted waits never see them)
+          [[maybe_unused]] d2 x0[CRIT ? NP : 1][4];
+          [[maybe_unused]] auto load_x = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int pn = decltype(pc)::value, tn = pn / PAIRS, t = pn % PAIRS;
+            const char* xr = xbase_c + static_cast<size_t>(tn) * 16 * ldx8;
+            asm volatile("" : "+s"(xr));
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            if (tn != 0) {
+            for (int r = 0; r < 4; ++r) {
+              if (r != 0) {
+                xr += ldx8;
+                asm volatile("" : "+s"(xr));
+              }
+              x0[pn][r] = load16_visible<256 * t>(xr, xlane_q);
+            }
+          };
+          if constexpr (CRIT) {
+            static_for<DEPTH>([&](auto pc) __attribute__((always_inline)) { load_x(pc); });
+          }
+          [[maybe_unused]] double q9h[9];
+          [[maybe_unused]] double ss[4] = {0.0, 0.0, 0.0, 0.0};
+          static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pn = decltype(pc)::value, tn = pn / PAIRS, t = pn % PAIRS;
+            if constexpr (t == 0 && tn != 0) {
               ct += 16 * ldy8;
               bt += 12 * ldb8;
               asm volatile("" : "+s"(ct), "+s"(bt));
             }
-            static_for<TM / 2>([&](auto tc) __attribute__((always_inline)) {
-              constexpr int t = decltype(tc)::value;
-              double b[2][3];
+            if constexpr (CRIT && t == 0) {
+              const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
 #pragma unroll
-              for (int e = 0; e < 2; ++e)
-                position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b[e]);
-              char* cb = ct;
+              for (int i = 0; i < 9; ++i) q9h[i] = 0.5 * qe[i];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                if (r != 0) {
-                  cb += ldy8;
-                  asm volatile("" : "+s"(cb));
-                }
-                if constexpr (ODD && t == TM / 2 - 1) {
-                  const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
-                  store16_sv<false, 256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
-                } else {
-                  store16_sv<false, 256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
-                }
+              for (int r = 0; r < 4; ++r) ss[r] = 0.0;
+            }
+            double b[2][3];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b[e]);
+            char* cb = ct;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (r != 0) {
+                cb += ldy8;
+                asm volatile("" : "+s"(cb));
               }
-              char* bb = bt;
-#pragma unroll
-              for (int a = 0; a < 3; ++a) {
-                if (a != 0) {
-                  bb += ldb8;
-                  asm volatile("" : "+s"(bb));
-                }
-                store16_sv<false, 256 * t>(bb, ylane_b, d2{b[0][a], b[1][a]});
+              if constexpr (ODD && t == TM / 2 - 1) {
+                const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
+                if constexpr (CRIT) store16_visible<256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
+                else store16_sv<false, 256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
+              } else {
+                if constexpr (CRIT) store16_visible<256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
+                else store16_sv<false, 256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
               }
-            });
-          }
+            }
+            char* bb = bt;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a != 0) {
+                bb += ldb8;
+                asm volatile("" : "+s"(bb));
+              }
+              if constexpr (CRIT) store16_visible<256 * t>(bb, ylane_b, d2{b[0][a], b[1][a]});
+              else store16_sv<false, 256 * t>(bb, ylane_b, d2{b[0][a], b[1][a]});
+            }
+            if constexpr (CRIT) {
+              const d2 P1v = legendre1(t);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const double x4[4] = {x0[pn][0][e], x0[pn][1][e], x0[pn][2][e], x0[pn][3][e]};
+                // (the one row that may not exist: the second of the wave's last pair, in its last lane)
+                const bool exists = !(ODD && t == TM / 2 - 1 && e == 1) || c != 15;
+                criterion(q9h, P1v[e], legendre2(P1v[e]), acc[2 * t + e][tn], x4, exists, ss);
+              }
+              if constexpr (pn + DEPTH < NP) load_x(std::integral_constant<int, (pn + DEPTH < NP ? pn + DEPTH : 0)>{});
+              if constexpr (t == PAIRS - 1) fold_columns(ss);
+            }
+          });
         };
         if (odd) emit(std::true_type{}); else emit(std::false_type{});
         return true;
@@ -1241,20 +1390,41 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const size_t col = col_base4 + tn * 16;
-      if (col >= q.m) continue;                                  // m is a multiple of 4: a rod is in or out as a whole
+      const bool rod_exists = col < q.m;                         // m is a multiple of 4: a rod is in or out as a whole
+      [[maybe_unused]] double q9h[9];
+      [[maybe_unused]] double ss[4] = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (CRIT) {
+        const double* qe = reinterpret_cast<const double*>(side) + ((wn * TN + tn) * 4 + g) * 9;
 #pragma unroll
-      for (int t = 0; t < TM / 2; ++t)
+        for (int i = 0; i < 9; ++i) q9h[i] = 0.5 * qe[i];
+      }
+#pragma unroll
+      for (int t = 0; t < TM / 2; ++t) {
+        [[maybe_unused]] d2 P1v = d2{0.0, 0.0};
+        if constexpr (CRIT) P1v = legendre1(t);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const uint32_t row = row_base + 32 * t + e;
-          if (row >= q.rows_out) continue;
-          double b[3];
-          position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b);
+          const bool exists = rod_exists && row < q.rows_out;
+          if (exists) {
+            double b[3];
+            position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) q.y[(col + r) * q.ldy + row] = acc[2 * t + e][tn][r];
+            for (int r = 0; r < 4; ++r) q.y[(col + r) * q.ldy + row] = acc[2 * t + e][tn][r];
 #pragma unroll
-          for (int a = 0; a < 3; ++a) q.y2[(col / 4 * 3 + a) * q.ldy2 + row] = b[a];
+            for (int a = 0; a < 3; ++a) q.y2[(col / 4 * 3 + a) * q.ldy2 + row] = b[a];
+          }
+          if constexpr (CRIT) {
+            double x4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (exists) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x4[r] = q.x[(col + r) * q.ldx + row];
+            }
+            criterion(q9h, P1v[e], legendre2(P1v[e]), acc[2 * t + e][tn], x4, exists, ss);
+          }
         }
+      }
+      if constexpr (CRIT) fold_columns(ss);
     }
     return false;
   };
@@ -1346,7 +1516,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool SADDR_STORES = SRI_STORE_SADDR != 0 && DMA && (!RANK1_EPI || R1X) && (ABL & 128) == 0 && EPI == EPI_NONE;
   auto store_tile = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
     if constexpr (EPI == EPI_QUAT) return store_tile_quat(tile);
-    if constexpr (EPI == EPI_QB) return store_tile_qb(tile);
+    if constexpr (QB) return store_tile_qb(tile);
     const ApplyArgs q = SRI_ARGS_HERE;
     uint32_t rb_c = tile / q.col_tiles;
     double* yp_ = q.y;
@@ -1515,7 +1685,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
   // (the fused quaternion epilogue of an odd-row-count operator issues the last row pair as two masked instructions: TN * 4 more)
   // (EPI_QB: three more columns per rod — 7 stores where the plain epilogue has 4)
-  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0) + (EPI == EPI_QB ? G::NSTORE * 3 / 4 : 0);
+  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0) + (QB ? G::NSTORE * 3 / 4 : 0);
   static_assert((AHEAD - 1) * G::DMA_PER_WAVE + TILE_STORES <= 63, "counted vmcnt must fit the 6-bit counter");
   constexpr int W_BOUNDARY = W_STEADY + TILE_STORES;        // ... plus one full tile's stores
   static_assert(AHEAD == 1 || AHEAD == 2, "the wait counts assume one or two stages in flight");
@@ -1877,6 +2047,24 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     }
   }
 
+  if constexpr (CRIT) {
+    // the wave's maxima -> the launch's words (NaN: the largest bit pattern a comparison of bits can see)
+    auto wave_max = [&](double v) __attribute__((always_inline)) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double other = __shfl_xor(v, off);
+        v = (other > v || other != other) ? other : v;
+      }
+      return (v != v) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(v));
+    };
+    const unsigned long long bd = wave_max(crit_dmax), b0 = wave_max(crit_seg0), b1 = wave_max(crit_seg1);
+    if (lane == 0 && p.crit != nullptr) {
+      if (bd != 0ull) atomicMax(p.crit, bd);
+      if (b0 != 0ull) atomicMax(p.crit + 1 + wm, b0);
+      if (b1 != 0ull) atomicMax(p.crit + 1 + G::WM + wm, b1);
+    }
+  }
+
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
@@ -2034,7 +2222,7 @@ static int prepare(int dev) {
   const auto kern = &apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>;
   // FOLD on the LDS-DMA path: x_base side buffer at the end; the epilogue form (whole k chunks): x_base and w side buffers
   constexpr int xb = (DMA && RANK1 && TAIL) ? G::XB_BYTES : ((DMA && RANK1 && !TAIL && EPI == EPI_NONE && G::R1X_OK && SRI_STORE_SADDR != 0) ? G::R1_BYTES : 0);
-  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
+  constexpr int lds = ((EPI == EPI_QUAT || EPI == EPI_QBC) ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) + xb;
   static_assert(lds <= 160 * 1024, "LDS request exceeds a CU");
   // the attribute is the most any launch of this kernel may ask for
   constexpr int lds_max = EPI != EPI_QUAT ? lds : (G::lds_bytes_quat(4) + xb <= 160 * 1024 ? G::lds_bytes_quat(4) + xb : G::lds_bytes_quat(2) + xb);
@@ -2067,7 +2255,7 @@ static int launch(ApplyArgs args, size_t col_tiles, int dev, int num_cus, uint32
     if (args.partial != nullptr && static_cast<size_t>(grid) * G::WN > *partials) return SRI_EINVAL;   // capacity
     *partials = grid * G::WN;
   }
-  constexpr int lds = (EPI == EPI_QUAT ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) +
+  constexpr int lds = ((EPI == EPI_QUAT || EPI == EPI_QBC) ? G::lds_bytes_quat(BUFS) : G::LDS_BYTES) +
                       ((DMA && RANK1 && TAIL) ? G::XB_BYTES : ((DMA && RANK1 && !TAIL && EPI == EPI_NONE && G::R1X_OK && SRI_STORE_SADDR != 0) ? G::R1_BYTES : 0));
   SRI_HIP(sri::launch_kernel((apply_kernel<G, DMA, RANK1, TAIL, false, 0, EPI, ASC, LEAN>), dim3(grid), dim3(G::THREADS), lds, stream, args));
   return SRI_OK;

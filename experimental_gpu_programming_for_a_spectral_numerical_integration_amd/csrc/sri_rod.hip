@@ -346,7 +346,7 @@ struct sri_rod_handle {
   uint32_t cap_partial = 0;
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
   // host side of that loop, owned by the handle (no per-call allocation, nothing to leak on an error return):
-  unsigned long long* h_state = nullptr;  // pinned, 2 slots x 4 words: the loop state read back per chunk
+  unsigned long long* h_state = nullptr;  // pinned, 24 words: 2 slots x 4 words, the loop state read back per chunk; from word 8 on the criterion of a closing product
   hipEvent_t done[2] = {nullptr, nullptr};
   sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64), else null
   bool use_resident = true;
@@ -372,6 +372,16 @@ struct sri_rod_handle {
                                           // Round 5: 0.25 -> 2 — the whole-panel bound after the first fine sweep does not move (3.0e-15 at N = 256 for
                                           // factors 0.25 ... 4: the last coarse sweeps contract factorially, the iterate is far better than its
                                           // criterion says), the coarse solve loses its last sweeps (N = 128, 131 072 rods: 1.57 -> 1.46 ms)
+  // Round 5, EPI_QBC: where the handle's closing product can also form the criterion (the 256-row tile geometry, odd row counts, at most
+  // 512 rows), the bound comes out of that launch — no read-only pass over Q and G.  seg_norms[i * nseg + B] = ||row i of Dn_NN^-1
+  // restricted to columns [64 B, 64 B + 64)||_2 (rounded up): with s_B = the largest 2-norm any column of d has over those 64 rows,
+  // |next update at row i| <= sum_B seg_norms[i][B] s_B (Cauchy-Schwarz segment by segment).
+  bool fused_criterion = true;            // SRI_ROD_OPT_FUSED_CRITERION
+  bool criterion_was_fused = false;       // the criterion the last solve returned came out of its closing product
+  std::vector<double> seg_norms;
+  uint32_t nseg = 0;
+  unsigned long long* d_crit = nullptr;   // two slots of sri::kCriterionWords words: a launch accumulates into one and zeroes the other
+  uint32_t crit_slot = 0;
   bool fused_position_rhs = true;         // sri_rod_integrate: the closing product also emits b = R(q) e1 where the handle has that variant
                                           // (SRI_ROD_OPT_FUSED_POSITION_RHS); the confirmation pass then only reads
 };
@@ -467,10 +477,12 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
       hipMemcpy(h->d_leg, leg.data(), sizeof(double) * leg.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc(&h->d_diff, 4 * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(h->d_diff, 0, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&h->d_crit, 2 * sri::kCriterionWords * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_crit, 0, 2 * sri::kCriterionWords * sizeof(unsigned long long)) != hipSuccess ||
       (h->cap_partial = sri::max_partials(integ)) == 0 ||
       hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial * 2) != hipSuccess ||     // two steps' worth: step k folds step k-1's
       hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 24 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[1], hipEventDisableTiming) != hipSuccess) {
     return SRI_ENOMEM;
@@ -499,6 +511,15 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
         worst = s2 > worst ? s2 : worst;
       }
       h->row_norm2 = static_cast<double>(sqrtl(worst)) * (1.0 + 0x1p-40);
+      // ... and the same row by row over segments of 64 columns (the criterion of the closing product, EPI_QBC)
+      h->nseg = (h->m + 63) / 64;
+      h->seg_norms.assign(static_cast<size_t>(h->m) * h->nseg, 0.0);
+      for (uint32_t i = 0; i < h->m; ++i)
+        for (uint32_t B = 0; B < h->nseg; ++B) {
+          long double s2 = 0.0L;
+          for (uint32_t k = 64 * B; k < h->m && k < 64 * B + 64; ++k) s2 += static_cast<long double>(A_fine[i + static_cast<size_t>(k) * h->m]) * A_fine[i + static_cast<size_t>(k) * h->m];
+          h->seg_norms[static_cast<size_t>(i) * h->nseg + B] = static_cast<double>(sqrtl(s2)) * (1.0 + 0x1p-40);
+        }
     }
     if (rc == SRI_OK) rc = sri::ivp_weights(integ, w_fine.data());
     if (rc == SRI_OK)
@@ -562,6 +583,10 @@ int sri_rod_set_option(sri_rod_t* h, int option, long value) {
     h->fused_position_rhs = value != 0;
     return SRI_OK;
   }
+  if (option == SRI_ROD_OPT_FUSED_CRITERION) {
+    h->fused_criterion = value != 0;
+    return SRI_OK;
+  }
   if (option == SRI_ROD_OPT_FIRST_SWEEP_CHECK) {
     h->first_sweep_check = value != 0;
     h->first_sweep_failed_tol = h->second_sweep_failed_tol = 0.0;
@@ -570,6 +595,14 @@ int sri_rod_set_option(sri_rod_t* h, int option, long value) {
   const int rc = sri_apply_set_option(h->integ, option, value);
   if (rc == SRI_OK && h->prolong != nullptr) (void)sri_apply_set_option(h->prolong, option, value);
   return rc;
+}
+
+int sri_rod_get_option(const sri_rod_t* h, int option, long* value) {
+  if (h == nullptr || h->integ == nullptr || value == nullptr) return SRI_EINVAL;
+  if (option == SRI_ROD_OPT_FUSED_POSITION_RHS) { *value = h->fused_position_rhs ? 1 : 0; return SRI_OK; }
+  if (option == SRI_ROD_OPT_FIRST_SWEEP_CHECK) { *value = h->first_sweep_check ? 1 : 0; return SRI_OK; }
+  if (option == SRI_ROD_OPT_FUSED_CRITERION) { *value = h->fused_criterion ? (h->criterion_was_fused ? 2 : 1) : 0; return SRI_OK; }
+  return sri_apply_get_option(h->integ, option, value);
 }
 
 int sri_rod_set_resident(sri_rod_t* h, int enable) {
@@ -592,6 +625,7 @@ int sri_rod_destroy(sri_rod_t* h) {
   for (double* b : bufs)
     if (b) (void)hipFree(b);
   if (h->d_diff) (void)hipFree(h->d_diff);
+  if (h->d_crit) (void)hipFree(h->d_crit);
   if (h->d_partial) (void)hipFree(h->d_partial);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->h_state) (void)hipHostFree(h->h_state);
@@ -802,8 +836,22 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   // The closing product: Q from the right-hand side `g` — and, for sri_rod_integrate, the position right-hand side from the same
   // accumulators where the handle has that kernel variant (b_emitted; otherwise the confirmation pass writes it)
   bool b_emitted = false;
+  bool crit_emitted = false;                                    // ... and the criterion (EPI_QBC): confirm() then launches nothing
+  uint32_t crit_slot_used = 0;
   auto closing_product = [&](const double* g) -> int {
     b_emitted = false;
+    crit_emitted = false;
+    if (h->emit_position_rhs && h->fused_position_rhs && h->fused_criterion && !h->seg_norms.empty() && h->nseg + 1 <= sri::kCriterionWords) {
+      const uint32_t slot = h->crit_slot;
+      sri::FixedPointCriterion cr{d_qe, h->d_leg, h->d_crit + slot * sri::kCriterionWords, h->d_crit + (slot ^ 1u) * sri::kCriterionWords};
+      const int r = sri::integrate_with_position_rhs(h->integ, g, ldw, h->d_xb4, dQ, ldq, h->d_B, ldw, cols, stream, &cr);
+      if (r == SRI_OK) {
+        b_emitted = crit_emitted = true;
+        crit_slot_used = slot;
+        h->crit_slot ^= 1u;                                     // (that launch zeroes the other slot)
+      }
+      if (r != SRI_EUNSUPPORTED) return r;
+    }
     if (h->emit_position_rhs && h->fused_position_rhs) {
       const int r = sri::integrate_with_position_rhs(h->integ, g, ldw, h->d_xb4, dQ, ldq, h->d_B, ldw, cols, stream);
       if (r == SRI_OK) b_emitted = true;
@@ -815,15 +863,18 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
     const unsigned blocks = static_cast<unsigned>(std::min<size_t>(2048, (rods + 3) / 4));                 // one wave per rod
     const size_t lds = 2 * static_cast<size_t>(m) * sizeof(double);                                       // (m <= 4095 fits 64 KiB)
     const uint32_t slot = h->diff_slot;
-    h->diff_slot ^= 1u;                                                                                    // (this launch clears the other slot)
+    if (!crit_emitted) h->diff_slot ^= 1u;                                                                 // (this launch clears the other slot)
     double* const nob = nullptr;
-    if (h->emit_position_rhs && !b_emitted)
+    if (crit_emitted)
+      ROD_HIP(hipMemcpyAsync(h_state + 8, h->d_crit + crit_slot_used * sri::kCriterionWords, sri::kCriterionWords * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, stream));
+    else if (h->emit_position_rhs && !b_emitted)
       ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel<true, false>, dim3(blocks), dim3(256), lds, stream, m, rods, h->d_nodes, d_qe, dQ,
                          ldq, g, ldw, h->d_diff, slot, h->d_B, ldw, nob, ldw));
     else
       ROD_HIP(sri::launch_kernel(sri::confirm_fixed_point_kernel<false, false>, dim3(blocks), dim3(256), lds, stream, m, rods, h->d_nodes, d_qe, dQ,
                          ldq, g, ldw, h->d_diff, slot, nob, ldw, nob, ldw));
-    ROD_HIP(hipMemcpyAsync(h_state, h->d_diff + 2 * slot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (!crit_emitted) ROD_HIP(hipMemcpyAsync(h_state, h->d_diff + 2 * slot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     h->positions_done = false;
     if (positions_behind && h->emit_position_rhs && h->pos_dR != nullptr) {
       // (sri_rod_integrate: the position product in front of the wait; if the bound then fails, the positions are formed again
@@ -840,6 +891,32 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       h->positions_done = true;
     }
     ROD_HIP(hipStreamSynchronize(stream));
+    h->criterion_was_fused = crit_emitted;
+    if (crit_emitted) {
+      // the criterion as the closing product left it: max |d|, and per 64-row segment the largest column sum of d^2
+      double dinf;
+      std::memcpy(&dinf, h_state + 8, sizeof(double));
+      bool nan = dinf != dinf;
+      double sB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t B = 0; B < h->nseg; ++B) {
+        double v;
+        std::memcpy(&v, h_state + 9 + B, sizeof(double));
+        nan = nan || v != v;
+        sB[B] = std::sqrt(v) * (1.0 + 0x1p-40);
+      }
+      if (nan) {
+        upd = NAN;
+      } else {
+        double worst = 0.0;
+        for (uint32_t i = 0; i < m; ++i) {
+          double s = 0.0;
+          for (uint32_t B = 0; B < h->nseg; ++B) s += h->seg_norms[static_cast<size_t>(i) * h->nseg + B] * sB[B];
+          worst = s > worst ? s : worst;
+        }
+        upd = std::fmin(dinf, worst * (1.0 + 0x1p-40));
+      }
+      return SRI_OK;
+    }
     double dinf, ss;
     std::memcpy(&dinf, h_state, sizeof(double));
     std::memcpy(&ss, h_state + 1, sizeof(double));

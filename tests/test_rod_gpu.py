@@ -401,6 +401,7 @@ def test_closing_product_emits_the_position_rhs_with_the_bits_of_the_separate_pa
     qe = torch.from_numpy(_qe_batch(rods, seed=31 * n + rods)).cuda()
     q_init, r_init = [0.6, 0.0, 0.8, 0.0], [1.0, -2.0, 0.5]
     rod = sri.RodIntegrator(n)
+    rod.set_option(sri.ROD_OPT_FUSED_CRITERION, 0)                       # (its own test below; here: the same criterion pass on both sides)
     out = []
     for fused in (1, 0):
         rod.set_option(sri.ROD_OPT_FUSED_POSITION_RHS, fused)
@@ -412,6 +413,44 @@ def test_closing_product_emits_the_position_rhs_with_the_bits_of_the_separate_pa
     R2 = rod.integrate_positions(out[0][0], r_init=r_init)               # the unfused composition, from the same quaternions
     torch.cuda.synchronize()
     assert torch.equal(out[0][1], R2)
+
+
+@pytest.mark.parametrize("n,rods", [(256, 700), (256, 4096), (256, 8200), (512, 300), (512, 1100), (300, 333), (400, 260), (128, 900), (1024, 100)])
+def test_closing_product_forms_the_criterion_of_the_fixed_point(sri, n, rods):
+    """Round 5 (EPI_QBC): where the closing product runs in the 256-row tile geometry on an odd row count of at most 511 (N = 256, 400,
+    512), it also forms d = 1/2 A(K) Q - G from its accumulators and leaves max |d| and, per 64-row segment, the largest column sum
+    of d^2 — the read-only pass over Q and G is gone.  Q, the position right-hand side and the positions keep their bits; the bound is
+    the same kind of bound (Cauchy-Schwarz segment by segment instead of column by column: close to the pass's figure, and rigorous —
+    one more unfused sweep moves no entry by more); N = 128, 300 (128-row tiles) and N = 1024 (ascending k) keep the pass."""
+    import torch
+
+    qe = torch.from_numpy(_qe_batch(rods, seed=17 * n + rods)).cuda()
+    q_init, r_init = [0.6, 0.0, 0.8, 0.0], [1.0, -2.0, 0.5]
+    rod = sri.RodIntegrator(n)
+    out = []
+    for crit in (1, 0):
+        rod.set_option(sri.ROD_OPT_FUSED_CRITERION, crit)
+        Q, R = rod.integrate(qe, q_init=q_init, r_init=r_init)
+        torch.cuda.synchronize()
+        used = rod.get_option(sri.ROD_OPT_FUSED_CRITERION)
+        assert used == ((2 if n in (256, 400, 512) else 1) if crit else 0), (n, crit, used)
+        assert rod.last_update <= 1e-14
+        out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+    if n in (256, 400, 512):
+        assert 0.5 <= out[0][3] / out[1][3] <= 2.0, (out[0][3], out[1][3])
+    else:
+        assert out[0][3] == out[1][3]
+    # the bound is a bound: the next sweep, unfused, from the returned iterate
+    Q = out[0][0]
+    K = rod.strain_field(qe)
+    G = rod.quaternion_rhs(K, Q)
+    integ = sri.SpectralApply(n, sri.OP_DNN_INV)
+    xb = torch.from_numpy(np.tile(np.array(q_init), (rods, 1))).cuda()
+    Qn = integ.integrate(G.reshape(rods * 4, n - 1), xb.reshape(-1)).reshape(rods, 4, n - 1)
+    moved = (Qn - Q).abs().max().item()
+    assert moved <= out[0][3] + np.sqrt(n) * 2.3e-16 * Q.abs().max().item(), (moved, out[0][3])
 
 
 @pytest.mark.parametrize("n,rods", [(32, 700), (48, 333), (64, 1500), (20, 64), (63, 40)])

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="force the streaming path (one fused launch per iteration) on small grids")
     ap.add_argument("--no-coarse-start", action="store_true", help="start the fixed point from q0 instead of the 16-node solution")
     ap.add_argument("--no-fused-position-rhs", action="store_true", help="the confirmation pass writes R(q) e1 instead of the closing product's epilogue")
+    ap.add_argument("--no-fused-criterion", action="store_true", help="a read-only pass forms the whole-panel criterion instead of the closing product's epilogue")
     ap.add_argument("--no-first-sweep-check", action="store_true", help="after a predicted start go straight to the fused loop (round 4's flow)")
     args = ap.parse_args()
     n, rods, m = args.n, args.rods, args.n - 1
@@ -60,6 +61,7 @@ def main():
     if not resident:
         rod.set_option(sri.ROD_OPT_FIRST_SWEEP_CHECK, 0 if args.no_first_sweep_check else 1)
         rod.set_option(sri.ROD_OPT_FUSED_POSITION_RHS, 0 if args.no_fused_position_rhs else 1)
+        rod.set_option(sri.ROD_OPT_FUSED_CRITERION, 0 if args.no_fused_criterion else 1)
     g = torch.Generator(device=dev).manual_seed(0x5EED)
     qe = (torch.rand((rods, 9), dtype=torch.float64, device=dev, generator=g) * 2 - 1) * args.scale
     # clock ramp
@@ -89,7 +91,7 @@ def main():
     res = {
         "metric": "rods/s (quaternion + position integration, fp64)", "value": rods / best, "unit": "rods/s",
         "n": n, "rods": rods, "path": "resident (one launch, state in LDS)" if resident else "streaming (one fused launch per iteration)",
-        "coarse_start": coarse_start, "first_sweep_check": not args.no_first_sweep_check, "fused_position_rhs": not args.no_fused_position_rhs, "qe_scale": args.scale, "tol": args.tol, "ms_total": best * 1e3, "picard_iterations": iters,
+        "coarse_start": coarse_start, "first_sweep_check": not args.no_first_sweep_check, "fused_position_rhs": not args.no_fused_position_rhs, "fused_criterion": not args.no_fused_criterion, "qe_scale": args.scale, "tol": args.tol, "ms_total": best * 1e3, "picard_iterations": iters,
         "last_update": rod.last_update,
         "unit_quaternion_defect_max": float((Q.pow(2).sum(dim=1).sqrt() - 1).abs().max()),
         "breakdown_ms": {"strain_field": ms_strain, "quaternion_rhs": ms_qrhs, "position_rhs": ms_prhs,
