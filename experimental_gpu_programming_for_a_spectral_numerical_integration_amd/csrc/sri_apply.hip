@@ -14,7 +14,7 @@ namespace sri {
 
 static_assert(plan::FLAT == GEO_FLAT && plan::MID == GEO_MID && plan::TALL == GEO_TALL && plan::WIDE == GEO_WIDE &&
               plan::WIDE32 == GEO_WIDE32 && plan::TALL_STRIP == GEO_TALL_STRIP && plan::G96 == GEO_96 && plan::G192 == GEO_192 && plan::G160 == GEO_160 && plan::G224 == GEO_224 &&
-              plan::TALL_MINI == GEO_TALL_MINI && plan::MID_MINI == GEO_MID_MINI, "sri_column_plan.h uses GeoId's values");
+              plan::TALL_MINI == GEO_TALL_MINI && plan::MID_MINI == GEO_MID_MINI && plan::FLAT_MINI == GEO_FLAT_MINI, "sri_column_plan.h uses GeoId's values");
 
 static thread_local int g_last_hip_error = 0;
 void record_hip_error(int hip_error) { g_last_hip_error = hip_error; }
@@ -180,7 +180,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       }
     }
     if (np != 0) {
-      static const char* const geo_names[12] = {"<64x64,dma>", "<128x128,dma>", "<256x128,dma>", "<64x256,dma>", "<32x256,dma>", "<256+16x128,dma>", "<96x128,dma>", "<192x64,dma>", "<160x64,dma>", "<224x64,dma>", "<256+4x128,dma>", "<128+4x128,dma>"};
+      static const char* const geo_names[13] = {"<64x64,dma>", "<128x128,dma>", "<256x128,dma>", "<64x256,dma>", "<32x256,dma>", "<256+16x128,dma>", "<96x128,dma>", "<192x64,dma>", "<160x64,dma>", "<224x64,dma>", "<256+4x128,dma>", "<128+4x128,dma>", "<64+4x64,dma>"};
       const double* wf = (rows % BK != 0) ? w_host : nullptr;
       h->parts_label = "sri_apply_mfma_f64";
       for (int i = 0; i < np && rc == SRI_OK; ++i) {
@@ -196,6 +196,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
           case GEO_224: rc = prepare_g224(device); break;
           case GEO_TALL_MINI: rc = prepare_mini(device); break;
           case GEO_MID_MINI: rc = prepare_midmini(device); break;
+          case GEO_FLAT_MINI: rc = prepare_flatmini(device); break;
           default: rc = prepare_strip(device); break;
         }
         if (rc != SRI_OK) break;
@@ -214,6 +215,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
             case GEO_224: pack_g224(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             case GEO_TALL_MINI: pack_mini(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             case GEO_MID_MINI: pack_midmini(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
+            case GEO_FLAT_MINI: pack_flatmini(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
             default: pack_strip(Ap, lda, part.rows, rows, h->nk, part.row_blocks, wp, h->ascending, pk); break;
           }
           h->parts_label += (i == 0 ? "" : "+");
@@ -230,7 +232,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       h->parts_name = h->parts_label.c_str();
       // (",lean": a part in a geometry that has lean twins took one — the 96 / 160 / 192-row blocks and the wide parts have none)
       bool any_lean_twin = false;
-      for (int i = 0; i < np; ++i) any_lean_twin = any_lean_twin || h->parts[i].geo == GEO_TALL || h->parts[i].geo == GEO_MID || h->parts[i].geo == GEO_TALL_STRIP || h->parts[i].geo == GEO_TALL_MINI || h->parts[i].geo == GEO_MID_MINI;
+      for (int i = 0; i < np; ++i) any_lean_twin = any_lean_twin || h->parts[i].geo == GEO_TALL || h->parts[i].geo == GEO_MID || h->parts[i].geo == GEO_TALL_STRIP || h->parts[i].geo == GEO_TALL_MINI || h->parts[i].geo == GEO_MID_MINI || h->parts[i].geo == GEO_FLAT_MINI;
       h->parts_label_lean = h->parts_label + (any_lean_twin ? ",lean" : "");
       h->parts_name_lean = h->parts_label_lean.c_str();
     }
@@ -435,6 +437,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
                         : part.geo == GEO_TALL_STRIP ? dispatch_strip(h, a, rank1, stream, lean)
                         : part.geo == GEO_TALL_MINI ? dispatch_mini(h, a, rank1, stream, lean)
                         : part.geo == GEO_MID_MINI ? dispatch_midmini(h, a, rank1, stream, lean)
+                        : part.geo == GEO_FLAT_MINI ? dispatch_flatmini(h, a, rank1, stream, lean)
                                              : (part.geo == GEO_MID ? dispatch_mid(h, a, dma, rank1, stream, nullptr, lean)
                                                                     : dispatch_tall(h, a, dma, rank1, stream, nullptr, lean));
         if (prc != SRI_OK) return prc;
@@ -578,6 +581,7 @@ static int measured_residency(int geo, int dev) {
     case GEO_TALL_STRIP: return resident_strip(dev);
     case GEO_TALL_MINI: return resident_mini(dev);
     case GEO_MID_MINI: return resident_midmini(dev);
+    case GEO_FLAT_MINI: return resident_flatmini(dev);
     case GEO_96: return resident_g96(dev);
     case GEO_192: return resident_g192(dev);
     case GEO_160: return resident_g160(dev);

@@ -53,6 +53,11 @@ int resident_g160(int dev);
 int resident_wide64(int dev);
 int resident_wide32(int dev);
 int resident_strip(int dev);
+int prepare_flatmini(int dev);
+int resident_flatmini(int dev);
+int dispatch_flatmini(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean);
+void pack_flatmini(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+                   std::vector<double>& out);
 int prepare_midmini(int dev);
 int resident_midmini(int dev);
 int dispatch_midmini(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean);

@@ -2135,6 +2135,12 @@ using GeoTallMini = Geo<4, 2, 4, 4, 3, 2>;
 // GeoMid + the mini strip: 129 ... 132 rows — N = 129, the 2^p + 1 grid of this size — as ONE 128-row block with its 1-4 leftover rows
 // on the 4x4x4 MFMA, two strip column tiles per wave (before: a 160-row block that is 81 % full)
 using GeoMidMini = Geo<2, 2, 4, 4, 2, 2>;
+// GeoFlat + the mini strip: 65 ... 68 rows — N = 65 — as ONE 64-row block with its 1-4 leftover rows (before: a 96-row block that is
+// two thirds full).  Two ring slots of 18 KiB: four workgroups per CU.
+#ifndef SRI_FLAT_MINI_STAGES
+#define SRI_FLAT_MINI_STAGES 2
+#endif
+using GeoFlatMini = Geo<1, 4, 4, 1, SRI_FLAT_MINI_STAGES, 2>;
 
 // BM 96 x BN 128, 4 waves side by side (96 x 32 each: six row tiles, two column tiles), two-slot ring (56 KiB, 2 WG per CU): operators
 // of 65-96 rows as ONE row block of their own height instead of a 128-row block that is a quarter to a half padding.  Plain and
@@ -2159,7 +2165,7 @@ using Geo224 = Geo<1, 4, 14, 1, 2>;
 // operators of 129-160 rows in ONE pass (before: 128 rows + a second launch at the copy rate; N = 160: 0.68 -> 0.77 of the peak)
 using Geo160 = Geo<1, 4, 10, 1, 2>;
 
-enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9, GEO_TALL_MINI = 10, GEO_MID_MINI = 11 };
+enum GeoId { GEO_FLAT = 0, GEO_MID = 1, GEO_TALL = 2, GEO_WIDE = 3, GEO_WIDE32 = 4, GEO_TALL_STRIP = 5, GEO_96 = 6, GEO_192 = 7, GEO_160 = 8, GEO_224 = 9, GEO_TALL_MINI = 10, GEO_MID_MINI = 11, GEO_FLAT_MINI = 12 };
 
 }  // namespace sri
 

@@ -82,4 +82,15 @@ void pack_midmini(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uin
   pack_operator<GeoMidMini>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
 }
 
+// the 64-row geometry with the mini strip (GeoFlatMini: 65 ... 68 rows)
+int prepare_flatmini(int dev) { return prepare_strip_geometry<GeoFlatMini>(dev); }
+int resident_flatmini(int dev) { return (dev < 0 || dev >= kMaxDevices) ? 0 : residency<GeoFlatMini, true, false, true>(dev).load(std::memory_order_acquire); }
+int dispatch_flatmini(sri_apply_t* h, const ApplyArgs& args, bool rank1, hipStream_t stream, bool lean) {
+  return dispatch_strip_geometry<GeoFlatMini>(h, args, rank1, stream, lean);
+}
+void pack_flatmini(const double* A, size_t lda, uint32_t rows, uint32_t kdim, uint32_t nk, uint32_t row_blocks, const double* w, bool asc,
+                   std::vector<double>& out) {
+  pack_operator<GeoFlatMini>(A, lda, rows, kdim, nk, row_blocks, w, asc, out);
+}
+
 }  // namespace sri

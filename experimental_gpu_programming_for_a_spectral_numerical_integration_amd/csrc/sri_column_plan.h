@@ -26,7 +26,7 @@ namespace sri {
 namespace plan {
 
 // ids as sri::GeoId (sri_apply_kernel.h)
-enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, G224 = 9, TALL_MINI = 10, MID_MINI = 11, GEO_COUNT = 12 };
+enum : int { FLAT = 0, MID = 1, TALL = 2, WIDE = 3, WIDE32 = 4, TALL_STRIP = 5, G96 = 6, G192 = 7, G160 = 8, G224 = 9, TALL_MINI = 10, MID_MINI = 11, FLAT_MINI = 12, GEO_COUNT = 13 };
 
 // ---- rows: the operator's own geometry, and the parts it is cut into (sri_apply.hip's create_from_matrix) ----------------------
 // Rows are tiled in blocks of 64 / 128 / 256 and a partly empty block costs a full one.  Above 256 rows the 128-row geometry is
@@ -52,7 +52,8 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
   // the rows behind the last full 256-row block: 1 ... 256 of them (all of the operator's rows when it has at most 256)
   const uint32_t full = rows > 256 ? (rows - 1) / 256 * 256 : 0, rest = rows - full;
   int last = -1;                                                   // geometry of a last part of `rest` rows (-1: none)
-  if (rest > 64 && rest <= 96) last = G96;                         // one row block of 96 ...
+  if (rest > 64 && rest <= 68 && allow_mini && allow_strip) last = FLAT_MINI;        // a 64-row block + its 1-4 leftover rows on the 4x4x4 MFMA (N = 65) ...
+  else if (rest > 64 && rest <= 96) last = G96;                    // ... one row block of 96 ...
   else if (rest > 128 && rest <= 132 && allow_mini && allow_strip) last = MID_MINI;   // ... a 128-row block + its 1-4 leftover rows on the 4x4x4 MFMA (N = 129) ...
   else if (rest > 128 && rest <= 160) last = G160;                 // ... of 160 (160 x 64 tiles) ...
   else if (rest > 160 && rest <= 192) last = G192;                 // ... or of 192 (192 x 64 tiles)
@@ -79,7 +80,7 @@ inline int row_parts(uint32_t rows, bool allow_strip, RowPart out[2], bool exten
 
 // rows of a tile of each geometry (the strip: 256 + 16)
 inline uint32_t tile_rows(int geo) {
-  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160, 224, 272, 144};
+  static const uint32_t bm[GEO_COUNT] = {64, 128, 256, 64, 32, 272, 96, 192, 160, 224, 272, 144, 80};
   return bm[geo];
 }
 
@@ -103,8 +104,9 @@ inline const GeoModel& model(int geo) {
       /* G192  192 x 64  */ {64, 2, {1.70, 3.20, 0, 0, 0}, 1.60, 0.0},     // (N = 192: 10.7 rounds in 408.5 us)
       /* G160  160 x 64  */ {64, 2, {1.50, 2.80, 0, 0, 0}, 1.40, 0.0},     // (N = 160: 12.8 rounds in 355.6 us)
       /* G224  224 x 64  */ {64, 2, {2.00, 3.75, 0, 0, 0}, 1.90, 0.0},     // (N = 224: 9.14 rounds in 480.7 us)
-      /* MMINI 128+4 x 128 */ {128, 2, {2.10, 4.20, 0, 0, 0}, 2.10, 0.0},    // (the 128-row geometry + eight 17-cycle MFMAs per stage and wave)
       /* MINI  256+4 x 128 */ {128, 1, {4.15, 0, 0, 0, 0}, 4.15, 0.0},    // (the tall geometry + four 17-cycle MFMAs per stage and wave; N = 257: 8 rounds x 17 chunks in 565 us)
+      /* MMINI 128+4 x 128 */ {128, 2, {2.10, 4.20, 0, 0, 0}, 2.10, 0.0},    // (the 128-row geometry + eight 17-cycle MFMAs per stage and wave)
+      /* FMINI  64+4 x 64  */ {64, 4, {0.70, 1.20, 1.95, 2.95, 0}, 0.52, 0.6},  // (the 64-row geometry + four 17-cycle MFMAs per stage and wave)
   };
   return table[geo];
 }

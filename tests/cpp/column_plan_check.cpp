@@ -101,11 +101,11 @@ int main() {
   {
     struct ExpectRows { uint32_t rows; int own; int np; int g0, g1; };
     const ExpectRows rows_table[] = {
-        {16, FLAT, 0, -1, -1},   {64, FLAT, 0, -1, -1},      {65, MID, 1, G96, -1},        {96, MID, 1, G96, -1},      {97, MID, 0, -1, -1},      {128, MID, 0, -1, -1},
+        {16, FLAT, 0, -1, -1},   {64, FLAT, 0, -1, -1},      {65, MID, 1, FLAT_MINI, -1},   {68, MID, 1, FLAT_MINI, -1},   {69, MID, 1, G96, -1},        {96, MID, 1, G96, -1},      {97, MID, 0, -1, -1},      {128, MID, 0, -1, -1},
         {129, TALL, 1, MID_MINI, -1}, {132, TALL, 1, MID_MINI, -1}, {133, TALL, 1, G160, -1},     {160, TALL, 1, G160, -1}, {161, TALL, 1, G192, -1},   {192, TALL, 1, G192, -1},
         {193, TALL, 1, G224, -1}, {224, TALL, 1, G224, -1}, {225, TALL, 0, -1, -1}, {255, TALL, 0, -1, -1},     {256, TALL, 0, -1, -1},       {257, MID, 1, TALL_MINI, -1},
         {260, MID, 1, TALL_MINI, -1}, {261, MID, 1, TALL_STRIP, -1}, {272, MID, 1, TALL_STRIP, -1}, {273, MID, 2, TALL, WIDE32}, {288, MID, 2, TALL, WIDE32}, {289, MID, 2, TALL, WIDE},
-        {320, MID, 2, TALL, WIDE}, {321, MID, 2, TALL, G96},  {352, MID, 2, TALL, G96},   {353, MID, 0, -1, -1},   {384, MID, 0, -1, -1},        {385, TALL, 2, TALL, MID_MINI}, {388, TALL, 2, TALL, MID_MINI}, {389, TALL, 2, TALL, G160},
+        {320, MID, 2, TALL, WIDE}, {321, MID, 2, TALL, FLAT_MINI}, {325, MID, 2, TALL, G96},  {352, MID, 2, TALL, G96},   {353, MID, 0, -1, -1},   {384, MID, 0, -1, -1},        {385, TALL, 2, TALL, MID_MINI}, {388, TALL, 2, TALL, MID_MINI}, {389, TALL, 2, TALL, G160},
         {416, TALL, 2, TALL, G160}, {417, TALL, 2, TALL, G192}, {448, TALL, 2, TALL, G192}, {449, TALL, 0, -1, -1},    {480, TALL, 0, -1, -1},
         {512, TALL, 0, -1, -1},  {513, MID, 2, TALL, TALL_MINI}, {517, MID, 2, TALL, TALL_STRIP}, {528, MID, 2, TALL, TALL_STRIP}, {529, MID, 2, TALL, WIDE32},
         {576, MID, 2, TALL, WIDE}, {600, MID, 2, TALL, G96},  {640, MID, 0, -1, -1},     {700, TALL, 2, TALL, G192},     {1024, TALL, 0, -1, -1},      {1025, MID, 2, TALL, TALL_MINI},
@@ -135,6 +135,8 @@ int main() {
           CHECK(rp[i].geo != TALL_STRIP || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 256 && rp[i].rows <= 272), "rows %u: strip of %u rows",
                 rows, rp[i].rows);
           CHECK(rp[i].geo != TALL_MINI || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 256 && rp[i].rows <= 260), "rows %u: mini strip of %u rows",
+                rows, rp[i].rows);
+          CHECK(rp[i].geo != FLAT_MINI || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 64 && rp[i].rows <= 68), "rows %u: flat mini strip of %u rows",
                 rows, rp[i].rows);
           CHECK(rp[i].geo != MID_MINI || (strip != 0 && rp[i].row_blocks == 1 && rp[i].rows > 128 && rp[i].rows <= 132), "rows %u: mid mini strip of %u rows",
                 rows, rp[i].rows);

@@ -77,12 +77,17 @@ WIDE_TALL = "256x128,dma>+<64x256"
 THIN_TALL = "256x128,dma>+<32x256"     # a last part of at most 32 rows
 STRIP1, STRIPN = "f64<256+16x128,dma>", "<256x128,dma>+<256+16x128,dma>"   # 256 a + r rows, r <= 16: the r rows ride with the last block
 MINI1, MININ = "f64<256+4x128,dma>", "<256x128,dma>+<256+4x128,dma>"         # ... r <= 4 (round 5): on the 4x4x4 MFMA
+FLATMINI = "<64+4x64,dma>"                                                    # 64 + r rows, r <= 4 (round 5): a 64-row block with its leftover rows
 MIDMINI = "<128+4x128,dma>"                                                   # 128 + r rows, r <= 4 (round 5): a 128-row block, two strip column tiles per wave
 
 
 @pytest.mark.parametrize("n,which,M,geometry", [
     (96, 0, 300, "<96x128,dma>"),    # 65 ... 96 rows (round 4): one 96-row block instead of a 128-row one
-    (66, 0, 515, "<96x128,dma>"),
+    (65, 0, 515, "f64" + FLATMINI),  # 65 ... 68 rows (round 5): one 64-row block + its 1-4 leftover rows on the 4x4x4 MFMA
+    (66, 0, 300, "f64" + FLATMINI),
+    (67, 1, 515, "f64" + FLATMINI),  # 66 rows of an integration operator: k tail
+    (69, 2, 130, "f64" + FLATMINI),  # Dn_NN of 69 nodes: 68 rows
+    (69, 0, 515, "<96x128,dma>"),
     (90, 1, 333, "<96x128,dma>"),    # 89 rows: k tail, the last wave's rows beyond 89 do not exist
     (97, 2, 130, "<96x128,dma>"),    # Dn_NN of a 97-node grid: 96 rows
     (98, 0, 200, "<128x128,dma>"),
@@ -100,6 +105,7 @@ MIDMINI = "<128+4x128,dma>"                                                   # 
     (320, 0, 700, WIDE_TALL),
     (321, 1, 260, WIDE_TALL),        # the integration operator of a 321-node grid: 320 rows
     (384, 0, 129, "<128x128,dma>"),  # 321 ... 384 rows: three 128-row blocks instead of two 256-row ones (round 3)
+    (321, 0, 200, "<256x128,dma>+" + FLATMINI),     # 256 + 65
     (352, 0, 200, "<256x128,dma>+<96x128,dma>"),    # 256 a + 65 ... 96 / 129 ... 192 rows (round 4): the full blocks in the 256-row geometry,
     (385, 0, 200, "<256x128,dma>+" + MIDMINI),      # ... the rest as a last part of its own height (129 rows: 128 + the mini strip)
     (390, 0, 200, "<256x128,dma>+<160x64,dma>"),
@@ -248,7 +254,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
 
     for n, which, M, ld_extra in [(96, 0, 1000, 1), (81, 1, 515, 0), (90, 1, 700, 3), (192, 0, 1000, 0), (177, 1, 515, 2), (180, 1, 700, 1), (200, 0, 1000, 1), (209, 1, 515, 0), (400, 0, 1000, 0), (417, 1, 515, 1), (350, 1, 515, 0), (700, 0, 300, 2), (300, 0, 1000, 0), (300, 1, 515, 0), (321, 1, 515, 3), (160, 0, 2049, 1), (1030, 0, 300, 0),
                                   (257, 0, 1000, 0), (258, 1, 777, 1), (273, 1, 515, 0), (520, 2, 300, 3),
-                                  (259, 1, 515, 2), (260, 0, 2049, 0), (129, 0, 1000, 1), (131, 1, 777, 0), (132, 0, 2049, 3), (385, 0, 515, 0), (388, 1, 300, 1), (899, 1, 200, 2), (516, 0, 300, 1), (1027, 2, 200, 0), (269, 0, 300, 0)]:
+                                  (259, 1, 515, 2), (260, 0, 2049, 0), (65, 0, 1000, 1), (67, 1, 777, 0), (68, 0, 2049, 3), (323, 1, 300, 1), (835, 0, 200, 2), (129, 0, 1000, 1), (131, 1, 777, 0), (132, 0, 2049, 3), (385, 0, 515, 0), (388, 1, 300, 1), (899, 1, 200, 2), (516, 0, 300, 1), (1027, 2, 200, 0), (269, 0, 300, 0)]:
         rows = n if which == 0 else n - 1
         X = uniform_panel(rows, M, seed=n)
         ops = []
@@ -269,7 +275,7 @@ def test_parts_give_the_bits_of_the_whole_operator(sri, oracle):
             torch.cuda.synchronize()
             assert torch.all(Yd[:, rows:] == -7.25)                  # the padding rows between columns are never written
             outs.append((Yd[:, :rows].clone(), tips, op.last_kernel))
-        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or "256+4" in outs[0][2] or "128+4" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64", "224x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "256+4", "128+4", "96x128", "192x64", "160x64", "224x64")), (outs[0][2], outs[1][2])
+        assert (">+<" in outs[0][2] or "256+16" in outs[0][2] or "256+4" in outs[0][2] or "128+4" in outs[0][2] or "64+4" in outs[0][2] or any(mark in outs[0][2] for mark in ("96x128", "192x64", "160x64", "224x64"))) and all(mark not in outs[1][2] for mark in (">+<", "256+16", "256+4", "128+4", "64+4", "96x128", "192x64", "160x64", "224x64")), (outs[0][2], outs[1][2])
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (n, which)
         assert torch.equal(outs[0][1], outs[0][0][:, 0])
         if which == 1:

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 txt = open(os.path.join(ROOT, "build/asm/resource_usage.txt")).read()
 isa = open(os.path.join(ROOT, "build/asm/sri_apply-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 GEO = {"1,4,4,1,3,0": "flat 64x64   Geo<1,4,4,1,3>", "2,2,4,4,2,0": "mid  128x128 Geo<2,2,4,4,2>", "4,2,4,4,3,0": "tall 256x128 Geo<4,2,4,4,3>",
-       "1,4,4,4,2,0": "wide 64x256  Geo<1,4,4,4,2>", "1,4,2,4,2,0": "wide 32x256  Geo<1,4,2,4,2>", "4,2,4,4,3,1": "strip 272x128 Geo<4,2,4,4,3,1>", "4,2,4,4,3,2": "mini 256+4x128 Geo<4,2,4,4,3,2>", "2,2,4,4,2,2": "mini 128+4x128 Geo<2,2,4,4,2,2>",
+       "1,4,4,4,2,0": "wide 64x256  Geo<1,4,4,4,2>", "1,4,2,4,2,0": "wide 32x256  Geo<1,4,2,4,2>", "4,2,4,4,3,1": "strip 272x128 Geo<4,2,4,4,3,1>", "4,2,4,4,3,2": "mini 256+4x128 Geo<4,2,4,4,3,2>", "2,2,4,4,2,2": "mini 128+4x128 Geo<2,2,4,4,2,2>", "1,4,4,1,2,2": "mini 64+4x64   Geo<1,4,4,1,2,2>",
        "1,4,6,2,2,0": "g96  96x128  Geo<1,4,6,2,2>", "1,4,10,1,2,0": "g160 160x64  Geo<1,4,10,1,2>", "2,2,6,2,2,0": "g192 192x64  Geo<2,2,6,2,2>",
        "1,4,14,1,2,0": "g224 224x64  Geo<1,4,14,1,2>"}
 SCR, OCC = r"ScratchSize \[bytes/lane\]", r"Occupancy \[waves/SIMD\]"
