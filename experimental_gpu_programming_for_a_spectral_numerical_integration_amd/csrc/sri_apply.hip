@@ -23,7 +23,9 @@ static const char* kernel_name(int geo, bool dma, bool quat = false, bool lean =
   // (the closing product of a rod solve, EPI_QB: Q and the position right-hand side from one launch; EPI_QBC: and the criterion — 256-row geometry)
   static const char* qb_names[4] = {"sri_apply_mfma_f64<256x128,dma,q+b>", "sri_apply_mfma_f64<256x128,dma,q+b,lean>",
                                     "sri_apply_mfma_f64<256x128,dma,q+b+criterion>", "sri_apply_mfma_f64<256x128,dma,q+b+criterion,lean>"};
+  static const char* qbc_mid_names[2] = {"sri_apply_mfma_f64<128x128,dma,q+b+criterion>", "sri_apply_mfma_f64<128x128,dma,q+b+criterion,lean>"};
   if (qb && geo == GEO_TALL) return qb_names[(lean ? 1 : 0) + (crit ? 2 : 0)];
+  if (qb && crit && geo == GEO_MID) return qbc_mid_names[lean ? 1 : 0];
   static const char* names[3][4] = {
       {"sri_apply_mfma_f64<64x64,reg>", "sri_apply_mfma_f64<64x64,dma>", "sri_apply_mfma_f64<64x64,reg,quat>",
        "sri_apply_mfma_f64<64x64,dma,quat>"},
@@ -305,12 +307,15 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     // (the variant exists for odd-row-count operators in the 256-row geometry, paired k order, LDS-DMA path: in 128 x 128 tiles —
     //  N = 128, and 257 ... 384 rows — three more stores per rod and row pair at every tile end cost what the lighter pass saves:
     //  profiles/r05_rod_ab_closing_product.log)
-    if (h->rows % 16 == 0 || h->rows < 16 || h->geo != GEO_TALL || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
+    // (with the criterion — EPI_QBC — the whole confirmation pass goes, and 128-row tiles take part: their two workgroups per CU cover
+    //  each other's tile ends)
+    const bool geo_ok = h->geo == GEO_TALL || (h->geo == GEO_MID && pos->crit != nullptr);
+    if (h->rows % 16 == 0 || h->rows < 16 || !geo_ok || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
     if (pos->crit != nullptr) {
       const FixedPointCriterion& cr = *pos->crit;
       if (cr.qe == nullptr || cr.leg1 == nullptr || cr.words == nullptr) return SRI_EINVAL;
       // (the criterion re-reads X as the accumulators sit: 16-byte pairs of rows, the last of which may reach one row past an odd row count)
-      if (ldx % 2 != 0 || reinterpret_cast<uintptr_t>(dX) % 16 != 0 || ldx < h->rows + (h->rows & 1u) || h->nk < 3 || h->row_blocks > 2) return SRI_EUNSUPPORTED;
+      if (ldx % 2 != 0 || reinterpret_cast<uintptr_t>(dX) % 16 != 0 || ldx < h->rows + (h->rows & 1u) || h->nk < 3) return SRI_EUNSUPPORTED;
     }
   }
   if (many == nullptr && M > 0 && (dX == nullptr || dY == nullptr)) return SRI_EINVAL;
@@ -549,6 +554,10 @@ int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, co
   if (h == nullptr || h->which != SRI_OP_DNN_INV || d_x_base == nullptr) return SRI_EINVAL;
   const PositionOut pos{dB, ldb, crit};
   return run(h, dG, ldg, dQ, ldq, M, d_x_base, static_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, nullptr, &pos);
+}
+
+uint32_t criterion_wave_rows(const sri_apply_t* h) {
+  return h == nullptr ? 0u : (h->geo == GEO_TALL ? static_cast<uint32_t>(GeoTall::WM) : (h->geo == GEO_MID ? static_cast<uint32_t>(GeoMid::WM) : 0u));
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,

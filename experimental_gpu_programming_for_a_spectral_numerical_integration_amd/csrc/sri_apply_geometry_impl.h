@@ -30,10 +30,10 @@ static int prepare_geometry(int dev) {
   if constexpr (G::BM >= 256 && G::STRIP == 0) {                // the closing product of a rod solve: Q and the position right-hand side
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QB, 0>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QB, 0, false, true>(dev);
-    if constexpr (G::QUAT_OK) {                                 // ... and the criterion of the fixed point
-      if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2>(dev);
-      if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2, false, true>(dev);
-    }
+  }
+  if constexpr (G::BM >= 128 && G::STRIP == 0 && G::QUAT_OK) {  // ... and the criterion of the fixed point (128-row tiles: only with it)
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2, false, true>(dev);
   }
   if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
@@ -59,18 +59,18 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const int cus = h->num_cus, dev = h->device;
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
-  if (args.y2 != nullptr) {                                       // EPI_QB (run() has checked that the handle is of that kind)
-    if constexpr (G::BM >= 256 && G::STRIP == 0) {
-      if (!dma || !tail || !rank1 || h->ascending || (args.qe != nullptr) != (args.crit != nullptr)) return SRI_EUNSUPPORTED;
-      if (args.crit != nullptr) {                                   // EPI_QBC: + the criterion of the fixed point
-        if constexpr (G::QUAT_OK) {
-          if (args.nk < 3 || args.row_blocks > 2) return SRI_EUNSUPPORTED;   // (two side buffers; two running maxima per wave)
-          return lean ? launch<G, true, true, true, EPI_QBC, 2, false, true>(args, col_tiles, dev, cus, cap, stream)
-                      : launch<G, true, true, true, EPI_QBC, 2>(args, col_tiles, dev, cus, cap, stream);
-        } else {
-          return SRI_EUNSUPPORTED;
-        }
+  if (args.y2 != nullptr) {                                       // EPI_QB / EPI_QBC (run() has checked that the handle is of that kind)
+    if (!dma || !tail || !rank1 || h->ascending || (args.qe != nullptr) != (args.crit != nullptr)) return SRI_EUNSUPPORTED;
+    if (args.crit != nullptr) {                                     // EPI_QBC: + the criterion of the fixed point
+      if constexpr (G::BM >= 128 && G::STRIP == 0 && G::QUAT_OK) {
+        if (args.nk < 3) return SRI_EUNSUPPORTED;                   // (two side buffers)
+        return lean ? launch<G, true, true, true, EPI_QBC, 2, false, true>(args, col_tiles, dev, cus, cap, stream)
+                    : launch<G, true, true, true, EPI_QBC, 2>(args, col_tiles, dev, cus, cap, stream);
+      } else {
+        return SRI_EUNSUPPORTED;
       }
+    }
+    if constexpr (G::BM >= 256 && G::STRIP == 0) {
       return lean ? launch<G, true, true, true, EPI_QB, 0, false, true>(args, col_tiles, dev, cus, cap, stream)
                   : launch<G, true, true, true, EPI_QB, 0>(args, col_tiles, dev, cus, cap, stream);
     } else {

@@ -66,10 +66,11 @@ int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t
 // accumulators the position right-hand side b = R(q) e1 of main.cpp:121-140 (dB: rows x 3 M / 4, ldb > rows when rows is odd) — one
 // launch (EPI_QB), the bits of sri_integrate followed by position_rhs_kernel.  M a multiple of 4.  SRI_EUNSUPPORTED where the handle
 // has no such variant (row counts that are multiples of 16, operators outside the 256-row tile geometry): the caller composes the two.
-// With `crit` (EPI_QBC; the 256-row geometry with at most two row blocks, ldg even and >= rows + 1, dG 16-byte aligned — else
-// SRI_EUNSUPPORTED): the same launch also forms d = 1/2 A(K) Q - G in registers (K = Phi(X_row) qe as integrate_quat_step does) and
-// leaves, by atomic max into words the caller has zeroed, words[0] = bits of max |d| and words[1 + 4 rb + wm] = bits of the largest
-// sum of d^2 that any column has over rows [256 rb + 64 wm, + 64) — segment_row_norms() has the matching norms of the operator's rows.
+// With `crit` (EPI_QBC; the 128- and 256-row geometries, odd row counts, paired k order, ldg even and >= rows + 1, dG 16-byte aligned
+// — else SRI_EUNSUPPORTED): the same launch also forms d = 1/2 A(K) Q - G in registers (K = Phi(X_row) qe as integrate_quat_step does)
+// and leaves, by atomic max into words the caller has zeroed, words[0] = bits of max |d| and, with W = criterion_wave_rows(h) wave rows
+// of 64 rows per row block, words[1 + wm] = bits of the largest sum of d^2 that any column has over rows [64 wm, 64 wm + 64) of row
+// block 0 and words[1 + W + wm] = the same over rows [BM rb + 64 wm, + 64) of ANY later row block (BM = 64 W rows per block).
 // `clear` (optional): kCriterionWords words that the launch zeroes for the caller's NEXT launch.
 constexpr uint32_t kCriterionWords = 9;
 struct FixedPointCriterion {
@@ -80,6 +81,7 @@ struct FixedPointCriterion {
 };
 int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, double* dQ, size_t ldq, double* dB,
                                 size_t ldb, size_t M, void* stream, const FixedPointCriterion* crit = nullptr);
+uint32_t criterion_wave_rows(const sri_apply_t* h);   // W above (4: 256-row tiles, 2: 128-row tiles; 0: the handle has no such variant)
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 int ivp_weights(const sri_apply_t* h, double* w_host);   // w = Dn_NN^-1 Dn_IN as the handle applies it (rows doubles); `device` current

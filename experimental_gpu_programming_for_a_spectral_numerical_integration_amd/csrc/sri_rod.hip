@@ -841,7 +841,7 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
   auto closing_product = [&](const double* g) -> int {
     b_emitted = false;
     crit_emitted = false;
-    if (h->emit_position_rhs && h->fused_position_rhs && h->fused_criterion && !h->seg_norms.empty() && h->nseg + 1 <= sri::kCriterionWords) {
+    if (h->emit_position_rhs && h->fused_position_rhs && h->fused_criterion && !h->seg_norms.empty() && sri::criterion_wave_rows(h->integ) != 0 && h->nseg <= 64) {
       const uint32_t slot = h->crit_slot;
       sri::FixedPointCriterion cr{d_qe, h->d_leg, h->d_crit + slot * sri::kCriterionWords, h->d_crit + (slot ^ 1u) * sri::kCriterionWords};
       const int r = sri::integrate_with_position_rhs(h->integ, g, ldw, h->d_xb4, dQ, ldq, h->d_B, ldw, cols, stream, &cr);
@@ -897,10 +897,13 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       double dinf;
       std::memcpy(&dinf, h_state + 8, sizeof(double));
       bool nan = dinf != dinf;
-      double sB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // (segment B = rows [64 B, 64 B + 64): wave row B % W of row block B / W; the launch keeps one maximum per wave row for row
+      //  block 0 and one for all later blocks together)
+      const uint32_t W = sri::criterion_wave_rows(h->integ);
+      double sB[64];                                              // (m <= 4095: at most 64 segments)
       for (uint32_t B = 0; B < h->nseg; ++B) {
         double v;
-        std::memcpy(&v, h_state + 9 + B, sizeof(double));
+        std::memcpy(&v, h_state + 9 + (B < W ? 0u : W) + B % W, sizeof(double));
         nan = nan || v != v;
         sB[B] = std::sqrt(v) * (1.0 + 0x1p-40);
       }

@@ -415,13 +415,15 @@ def test_closing_product_emits_the_position_rhs_with_the_bits_of_the_separate_pa
     assert torch.equal(out[0][1], R2)
 
 
-@pytest.mark.parametrize("n,rods", [(256, 700), (256, 4096), (256, 8200), (512, 300), (512, 1100), (300, 333), (400, 260), (128, 900), (1024, 100)])
+@pytest.mark.parametrize("n,rods", [(256, 700), (256, 4096), (256, 8200), (512, 300), (512, 1100), (300, 333), (400, 260), (128, 900), (128, 4100), (200, 500),
+                                    (100, 64), (1024, 100)])
 def test_closing_product_forms_the_criterion_of_the_fixed_point(sri, n, rods):
-    """Round 5 (EPI_QBC): where the closing product runs in the 256-row tile geometry on an odd row count of at most 511 (N = 256, 400,
-    512), it also forms d = 1/2 A(K) Q - G from its accumulators and leaves max |d| and, per 64-row segment, the largest column sum
-    of d^2 — the read-only pass over Q and G is gone.  Q, the position right-hand side and the positions keep their bits; the bound is
+    """Round 5 (EPI_QBC): where the closing product runs in the 128- or 256-row tile geometry on an odd row count in the paired k order
+    (N = 100 ... 512 here: one to three row blocks, full and partial), it also forms d = 1/2 A(K) Q - G from its accumulators and leaves
+    max |d| and, per 64-row segment, the largest column sum of d^2 — the read-only pass over Q and G is gone.  Q, the position right-hand side and the positions keep their bits; the bound is
     the same kind of bound (Cauchy-Schwarz segment by segment instead of column by column: close to the pass's figure, and rigorous —
-    one more unfused sweep moves no entry by more); N = 128, 300 (128-row tiles) and N = 1024 (ascending k) keep the pass."""
+    one more unfused sweep moves no entry by more).  (The integration operator keeps the paired k order at every size: N = 1024, four row
+    blocks, takes part.)"""
     import torch
 
     qe = torch.from_numpy(_qe_batch(rods, seed=17 * n + rods)).cuda()
@@ -433,15 +435,12 @@ def test_closing_product_forms_the_criterion_of_the_fixed_point(sri, n, rods):
         Q, R = rod.integrate(qe, q_init=q_init, r_init=r_init)
         torch.cuda.synchronize()
         used = rod.get_option(sri.ROD_OPT_FUSED_CRITERION)
-        assert used == ((2 if n in (256, 400, 512) else 1) if crit else 0), (n, crit, used)
+        assert used == (2 if crit else 0), (n, crit, used)
         assert rod.last_update <= 1e-14
         out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2]
-    if n in (256, 400, 512):
-        assert 0.5 <= out[0][3] / out[1][3] <= 2.0, (out[0][3], out[1][3])
-    else:
-        assert out[0][3] == out[1][3]
+    assert 0.4 <= out[0][3] / out[1][3] <= 2.5, (out[0][3], out[1][3])
     # the bound is a bound: the next sweep, unfused, from the returned iterate
     Q = out[0][0]
     K = rod.strain_field(qe)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-5 batch 19: EPI_QBC on 128-row tiles too (N = 128, 300) — rod tests, then the solve with / without the fused criterion
+python -m pytest tests/test_rod_gpu.py -m gpu -x -q > gpurun_out/r05_qbc_tests5.log 2>&1
+rc=$?; tail -3 gpurun_out/r05_qbc_tests5.log
+[ $rc -eq 0 ] || exit $rc
+for rep in 1 2; do
+for n in 128:131072 300:49152 256:65536 100:131072 1024:8192; do
+  for f in "" "--no-fused-criterion"; do
+    python tools/rod_bench.py --n ${n%%:*} --rods ${n##*:} --no-cpu $f 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['n'], d['rods'], 'fused_criterion', d['fused_criterion'], round(d['ms_total'],4), d['last_update'])" >> gpurun_out/r05_rod_ab_fused_criterion_mid.log
+  done
+done
+done
+cat gpurun_out/r05_rod_ab_fused_criterion_mid.log
