@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 batch 13: the 128-row geometry with the mini strip (129 ... 132 rows) — tests of the new cases, then A/B against the 160 x 64 block
+# ab_mini_strip_128_rows.sh — the 128-row geometry with the mini strip (129 ... 132 rows): the geometry tests, then A/B against the 160 x 64 block (SRI_DEBUG=mini=0)
 L=experimental_gpu_programming_for_a_spectral_numerical_integration_amd/libsri_hip.so
 python -m pytest tests/test_apply_gpu.py -m gpu -x -q -k "geometry_above or parts_give" > gpurun_out/r05_midmini_tests.log 2>&1
 rc=$?; tail -3 gpurun_out/r05_midmini_tests.log
