@@ -310,7 +310,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     // (with the criterion — EPI_QBC — the whole confirmation pass goes, and 128-row tiles take part: their two workgroups per CU cover
     //  each other's tile ends)
     const bool geo_ok = h->geo == GEO_TALL || (h->geo == GEO_MID && pos->crit != nullptr);
-    if (h->rows % 16 == 0 || h->rows < 16 || !geo_ok || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
+    // (whole k chunks — rows % 16 == 0, the N = 16 q + 1 grids — only with the criterion: that variant applies the rank-1 term itself)
+    if ((h->rows % 16 == 0 && pos->crit == nullptr) || h->rows < 16 || !geo_ok || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
     if (pos->crit != nullptr) {
       const FixedPointCriterion& cr = *pos->crit;
       if (cr.qe == nullptr || cr.leg1 == nullptr || cr.words == nullptr) return SRI_EINVAL;

@@ -34,6 +34,7 @@ static int prepare_geometry(int dev) {
   if constexpr (G::BM >= 128 && G::STRIP == 0 && G::QUAT_OK) {  // ... and the criterion of the fixed point (128-row tiles: only with it)
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2>(dev);
     if (rc == SRI_OK) rc = prepare<G, true, true, true, EPI_QBC, 2, false, true>(dev);
+    if (rc == SRI_OK) rc = prepare<G, true, true, false, EPI_QBC, 2>(dev);           // whole k chunks (N = 16 q + 1 grids): the rank-1 term in the store stage
   }
   if constexpr (G::BM >= 128) {                                 // the lean twins of the odd-row-count variants (see run())
     if (rc == SRI_OK) rc = prepare<G, true, false, true, EPI_NONE, 0, false, true>(dev);
@@ -60,10 +61,11 @@ static int dispatch(sri_apply_t* h, const ApplyArgs& args, bool dma, bool rank1,
   const uint32_t cap = h->max_workgroups;
   const bool tail = args.tail_k != 0 || (SRI_TAIL_ABL & 8) != 0;   // (ablation 8: the TAIL instantiation for every operator)
   if (args.y2 != nullptr) {                                       // EPI_QB / EPI_QBC (run() has checked that the handle is of that kind)
-    if (!dma || !tail || !rank1 || h->ascending || (args.qe != nullptr) != (args.crit != nullptr)) return SRI_EUNSUPPORTED;
+    if (!dma || !rank1 || h->ascending || (args.qe != nullptr) != (args.crit != nullptr) || (!tail && args.crit == nullptr)) return SRI_EUNSUPPORTED;
     if (args.crit != nullptr) {                                     // EPI_QBC: + the criterion of the fixed point
       if constexpr (G::BM >= 128 && G::STRIP == 0 && G::QUAT_OK) {
         if (args.nk < 3) return SRI_EUNSUPPORTED;                   // (two side buffers)
+        if (!tail) return launch<G, true, true, false, EPI_QBC, 2>(args, col_tiles, dev, cus, cap, stream);
         return lean ? launch<G, true, true, true, EPI_QBC, 2, false, true>(args, col_tiles, dev, cus, cap, stream)
                     : launch<G, true, true, true, EPI_QBC, 2>(args, col_tiles, dev, cus, cap, stream);
       } else {

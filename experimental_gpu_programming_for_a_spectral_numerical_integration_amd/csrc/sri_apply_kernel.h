@@ -322,6 +322,13 @@ __device__ __forceinline__ d2 load16_visible(const char* uniform_base, uint32_t 
   return *reinterpret_cast<const __attribute__((address_space(1))) d2_a8*>(gp + static_cast<size_t>(lane_offset) + OFFSET);
 }
 
+// A plain load through a pointer that came out of the argument block, in the GLOBAL address space (the compiler cannot prove it and
+// would emit flat loads, which it can only wait for with vmcnt(0) lgkmcnt(0)).
+template <class T>
+__device__ __forceinline__ T load_global(const T* p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
 // The two doubles of a 16-byte Y store come from two different accumulators and have to be copied side by side:
 // two 64-bit moves instead of the four 32-bit ones hipcc emits for the tuple (every VALU instruction costs MFMA time).
 __device__ __forceinline__ d2 pack2(double lo, double hi) {
@@ -474,6 +481,8 @@ __device__ __forceinline__ void wait_stage_and_barrier() {
 //           buffers) and compared with the right-hand side the product was formed from — the X panel itself, re-read in the accumulator
 //           layout — so that max |G' - X| and the column sums of (G' - X)^2 over each wave's 64 rows leave the launch in a few words:
 //           what confirm_fixed_point_kernel (sri_rod.hip) reads 8 doubles per rod and node for.
+//           Also instantiated without TAIL (row counts that are multiples of 16: the N = 16 q + 1 grids), where the rank-1 term is not in
+//           the product: the store stage applies it first — one fused multiply-add per element, as the plain epilogue does.
 enum { EPI_NONE = 0, EPI_QUAT = 1, EPI_QB = 2, EPI_QBC = 3 };
 #ifndef SRI_QBC_DEPTH
 #define SRI_QBC_DEPTH 2              // EPI_QBC: row pairs of X in flight ahead of the one whose criterion is being formed (A/B knob)
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr bool QB = EPI == EPI_QB || EPI == EPI_QBC;          // Q and b = R(q) e1 leave the launch
   constexpr bool CRIT = EPI == EPI_QBC;                         // ... and the criterion of the fixed point
   constexpr bool QSIDE = EPI == EPI_QUAT || EPI == EPI_QBC;     // strain coefficients and Legendre factors of a tile travel through the side buffers
-  static_assert(!QB || (DMA && TAIL && G::STRIP == 0), "EPI_QB: odd-row-count operators on the LDS-DMA path (the rank-1 term rides in the product)");
+  static_assert(!QB || (DMA && G::STRIP == 0 && (TAIL || EPI == EPI_QBC)),
+                "EPI_QB: odd-row-count operators on the LDS-DMA path (the rank-1 term rides in the product); EPI_QBC also takes whole k chunks (the term is applied here)");
   static_assert(!QSIDE || G::QUAT_OK, "ring + side buffers of the fused quaternion epilogue do not fit this geometry");
   // Whenever the last k chunk has a free slot (rows % 16 != 0: every integration operator of an N = 2^p grid, and the
   // register-staged build, which only serves rows < 16) the rank-1 term rides in the product itself: the host packs -w
@@ -1324,6 +1334,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
           }
           [[maybe_unused]] double q9h[9];
           [[maybe_unused]] double ss[4] = {0.0, 0.0, 0.0, 0.0};
+          [[maybe_unused]] double xbq[4] = {0.0, 0.0, 0.0, 0.0};      // x_base of this lane's rod in rod group tn (RANK1_EPI)
           static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int pn = decltype(pc)::value, tn = pn / PAIRS, t = pn % PAIRS;
             if constexpr (t == 0 && tn != 0) {
@@ -1338,10 +1349,23 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
               for (int r = 0; r < 4; ++r) ss[r] = 0.0;
             }
+            // the quaternions of the pair: the accumulators themselves (FOLD), or with the initial-value term applied here (whole k chunks:
+            // N = 16 q + 1 grids) — one more fused multiply-add of each element's chain, as the plain epilogue applies it
+            d4 qv[2] = {acc[2 * t][tn], acc[2 * t + 1][tn]};
+            if constexpr (RANK1_EPI) {
+              if constexpr (t == 0) {
+                const d2 x01 = load_global(reinterpret_cast<const d2*>(q.xb + col_base4 + tn * 16)), x23 = load_global(reinterpret_cast<const d2*>(q.xb + col_base4 + tn * 16 + 2));
+                xbq[0] = x01[0]; xbq[1] = x01[1]; xbq[2] = x23[0]; xbq[3] = x23[1];
+              }
+              const d2 wv = load_global(reinterpret_cast<const d2*>(q.w + row_base + 32 * t));
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qv[e][r] = __builtin_fma(-wv[e], xbq[r], qv[e][r]);
+            }
             double b[2][3];
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-              position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b[e]);
+            for (int e = 0; e < 2; ++e) position_rhs(qv[e][0], qv[e][1], qv[e][2], qv[e][3], b[e]);
             char* cb = ct;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1350,12 +1374,13 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 asm volatile("" : "+s"(cb));
               }
               if constexpr (ODD && t == TM / 2 - 1) {
+                static_assert(!(ODD && RANK1_EPI), "an odd row count folds the rank-1 term into the product");
                 const double above = row_above(acc[t > 0 ? 2 * t - 1 : 0][tn][r], acc[2 * t + 1][tn][r]);
                 if constexpr (CRIT) store16_visible<256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
                 else store16_sv<false, 256 * t - 8>(cb, ylane_q, pack2(above, acc[2 * t][tn][r]));
               } else {
-                if constexpr (CRIT) store16_visible<256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
-                else store16_sv<false, 256 * t>(cb, ylane_q, pack2(acc[2 * t][tn][r], acc[2 * t + 1][tn][r]));
+                if constexpr (CRIT) store16_visible<256 * t>(cb, ylane_q, pack2(qv[0][r], qv[1][r]));
+                else store16_sv<false, 256 * t>(cb, ylane_q, pack2(qv[0][r], qv[1][r]));
               }
             }
             char* bb = bt;
@@ -1375,14 +1400,18 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
                 const double x4[4] = {x0[pn][0][e], x0[pn][1][e], x0[pn][2][e], x0[pn][3][e]};
                 // (the one row that may not exist: the second of the wave's last pair, in its last lane)
                 const bool exists = !(ODD && t == TM / 2 - 1 && e == 1) || c != 15;
-                criterion(q9h, P1v[e], legendre2(P1v[e]), acc[2 * t + e][tn], x4, exists, ss);
+                criterion(q9h, P1v[e], legendre2(P1v[e]), qv[e], x4, exists, ss);
               }
               if constexpr (pn + DEPTH < NP) load_x(std::integral_constant<int, (pn + DEPTH < NP ? pn + DEPTH : 0)>{});
               if constexpr (t == PAIRS - 1) fold_columns(ss);
             }
           });
         };
-        if (odd) emit(std::true_type{}); else emit(std::false_type{});
+        if constexpr (TAIL) {
+          if (odd) emit(std::true_type{}); else emit(std::false_type{});
+        } else {
+          emit(std::false_type{});                                // (whole k chunks: rows % 16 == 0, no half-empty pair)
+        }
         return true;
       }
     }
@@ -1406,11 +1435,19 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         for (int e = 0; e < 2; ++e) {
           const uint32_t row = row_base + 32 * t + e;
           const bool exists = rod_exists && row < q.rows_out;
+          d4 qs = acc[2 * t + e][tn];
+          if constexpr (RANK1_EPI) {
+            if (exists) {
+              const double wv = q.w[row];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) qs[r] = __builtin_fma(-wv, q.xb[col + r], qs[r]);
+            }
+          }
           if (exists) {
             double b[3];
-            position_rhs(acc[2 * t + e][tn][0], acc[2 * t + e][tn][1], acc[2 * t + e][tn][2], acc[2 * t + e][tn][3], b);
+            position_rhs(qs[0], qs[1], qs[2], qs[3], b);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q.y[(col + r) * q.ldy + row] = acc[2 * t + e][tn][r];
+            for (int r = 0; r < 4; ++r) q.y[(col + r) * q.ldy + row] = qs[r];
 #pragma unroll
             for (int a = 0; a < 3; ++a) q.y2[(col / 4 * 3 + a) * q.ldy2 + row] = b[a];
           }
@@ -1420,7 +1457,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
 #pragma unroll
               for (int r = 0; r < 4; ++r) x4[r] = q.x[(col + r) * q.ldx + row];
             }
-            criterion(q9h, P1v[e], legendre2(P1v[e]), acc[2 * t + e][tn], x4, exists, ss);
+            criterion(q9h, P1v[e], legendre2(P1v[e]), qs, x4, exists, ss);
           }
         }
       }

@@ -66,8 +66,9 @@ int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t
 // accumulators the position right-hand side b = R(q) e1 of main.cpp:121-140 (dB: rows x 3 M / 4, ldb > rows when rows is odd) — one
 // launch (EPI_QB), the bits of sri_integrate followed by position_rhs_kernel.  M a multiple of 4.  SRI_EUNSUPPORTED where the handle
 // has no such variant (row counts that are multiples of 16, operators outside the 256-row tile geometry): the caller composes the two.
-// With `crit` (EPI_QBC; the 128- and 256-row geometries, odd row counts, paired k order, ldg even and >= rows + 1, dG 16-byte aligned
-// — else SRI_EUNSUPPORTED): the same launch also forms d = 1/2 A(K) Q - G in registers (K = Phi(X_row) qe as integrate_quat_step does)
+// With `crit` (EPI_QBC; the 128- and 256-row geometries, paired k order, at least three k chunks, ldg even and >= rows + rows % 2, dG
+// 16-byte aligned — else SRI_EUNSUPPORTED; row counts that are multiples of 16 take part only in this form, which then applies the
+// rank-1 term in its store stage): the same launch also forms d = 1/2 A(K) Q - G in registers (K = Phi(X_row) qe as integrate_quat_step does)
 // and leaves, by atomic max into words the caller has zeroed, words[0] = bits of max |d| and, with W = criterion_wave_rows(h) wave rows
 // of 64 rows per row block, words[1 + wm] = bits of the largest sum of d^2 that any column has over rows [64 wm, 64 wm + 64) of row
 // block 0 and words[1 + W + wm] = the same over rows [BM rb + 64 wm, + 64) of ANY later row block (BM = 64 W rows per block).

@@ -265,11 +265,12 @@ int sri_rod_set_predictor(sri_rod_t *h, int enable);
                                               writes the position right-hand side R(q) e1 from its accumulators where the handle
                                               has that kernel variant (odd row counts in the 256-row tile geometry: N = 256, 512, 1024 ...); 0: a separate pass
                                               writes it.  Same bits                                                           */
-#define SRI_ROD_OPT_FUSED_CRITERION 102 /* 1 (default): where that product can (the 256-row tile geometry, odd row counts up to 511:
-                                           N = 256, 512, ...), it also forms the whole-panel criterion 1/2 A(K) Q - G from its
-                                           accumulators, and no separate pass reads Q and G back; 0: the read-only pass.  The same
-                                           fixed point; `last_update` is a rigorous bound either way (64-row segments of the
-                                           Cauchy-Schwarz bound instead of whole columns: within ~15 % of each other)        */
+#define SRI_ROD_OPT_FUSED_CRITERION 102 /* 1 (default): where that product can (operators of more than 64 rows in the paired k order — every
+                                           integration operator the rod handle builds for N > 64), it also forms the whole-panel
+                                           criterion 1/2 A(K) Q - G from its accumulators, and no separate pass reads Q and G back;
+                                           0: the read-only pass.  The same fixed point; `last_update` is a rigorous bound either
+                                           way (Cauchy-Schwarz over 64-row segments instead of whole columns: within ~30 % of each
+                                           other, neither always the smaller)                                               */
 int sri_rod_set_option(sri_rod_t *h, int option, long value);
 /* The current value of a switch (apply options: as the integration operator's handle has them).  SRI_ROD_OPT_FUSED_CRITERION reads 2
  * when the criterion of the LAST solve on this handle came out of its closing product. */

@@ -416,14 +416,15 @@ def test_closing_product_emits_the_position_rhs_with_the_bits_of_the_separate_pa
 
 
 @pytest.mark.parametrize("n,rods", [(256, 700), (256, 4096), (256, 8200), (512, 300), (512, 1100), (300, 333), (400, 260), (128, 900), (128, 4100), (200, 500),
-                                    (100, 64), (1024, 100)])
+                                    (100, 64), (1024, 100), (129, 900), (257, 700), (257, 4100), (513, 300), (81, 500), (401, 260)])
 def test_closing_product_forms_the_criterion_of_the_fixed_point(sri, n, rods):
     """Round 5 (EPI_QBC): where the closing product runs in the 128- or 256-row tile geometry on an odd row count in the paired k order
     (N = 100 ... 512 here: one to three row blocks, full and partial), it also forms d = 1/2 A(K) Q - G from its accumulators and leaves
     max |d| and, per 64-row segment, the largest column sum of d^2 — the read-only pass over Q and G is gone.  Q, the position right-hand side and the positions keep their bits; the bound is
     the same kind of bound (Cauchy-Schwarz segment by segment instead of column by column: close to the pass's figure, and rigorous —
     one more unfused sweep moves no entry by more).  (The integration operator keeps the paired k order at every size: N = 1024, four row
-    blocks, takes part.)"""
+    blocks, takes part; on N = 16 q + 1 grids — whole k chunks: N = 81, 129, 257, 401, 513 — the variant applies the initial-value term in
+    its store stage like the plain epilogue.)"""
     import torch
 
     qe = torch.from_numpy(_qe_batch(rods, seed=17 * n + rods)).cuda()
