@@ -498,8 +498,11 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   };
   // The cost model ranks candidates with ONE device's tile times (sri_column_plan.h).  Where it wants to deviate from the
   // operator's own geometry, the first call at this column count lets THIS device decide: both schedules run on the call's own
-  // panel (they write the same bits), own - planned - planned - own between five events, and the handle remembers which one
-  // was faster (a tie within 3 % goes to the own geometry).  Plain applies and sri_integrate only (a fused step must run once);
+  // panel (they write the same bits) — once each untimed (code loads, first touches, the clock leaving its idle state), then
+  // own - planned - planned - own between five events, the two of each kind ADDED (a clock that is still ramping drifts through
+  // the four launches: in the sums a linear drift cancels; round 5's first cut compared the minima, and a first call on a cold
+  // device — own first and LAST — gave the verdict to the own geometry where the plan is 7 % faster: N = 320, 385 in
+  // profiles/r05_sweep_n.jsonl of two boxes) — and the handle remembers which one was faster (a tie within 3 % goes to the own geometry).  Plain applies and sri_integrate only (a fused step must run once);
   // never inside a stream capture (the model decides there); SRI_OPT_PLAN_CALIBRATION = 0 trusts the model everywhere.
   if (choice.alt >= 0 && quat == nullptr && h->plan_calibrate) {
     plan::Choice own_only;
@@ -517,6 +520,9 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       for (hipEvent_t& e : h->plan_events)
         if (e == nullptr) SRI_HIP(hipEventCreate(&e));
       const plan::Choice* order[4] = {&own_only, &choice, &choice, &own_only};
+      rc = execute(own_only);
+      if (rc == SRI_OK) rc = execute(choice);
+      if (rc != SRI_OK) return rc;
       SRI_HIP(hipEventRecord(h->plan_events[0], stream));
       for (int i = 0; i < 4; ++i) {
         rc = execute(*order[i]);
@@ -531,8 +537,8 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       if (h->plan_verdict_count < sri_apply_handle::kPlanVerdicts) ++h->plan_verdict_count;
       v.cols = M;
       v.rank1 = rank1;
-      v.own_us = 1e3f * std::min(t[0], t[3]);
-      v.plan_us = 1e3f * std::min(t[1], t[2]);
+      v.own_us = 1e3f * 0.5f * (t[0] + t[3]);
+      v.plan_us = 1e3f * 0.5f * (t[1] + t[2]);
       v.use_plan = v.plan_us < 0.97f * v.own_us;
       if (!v.use_plan) h->last_kernel.store(in_parts ? (lean_for(0, M) ? h->parts_name_lean : h->parts_name)
                                                      : kernel_name(h->geo, dma, false, lean_for(0, M)), std::memory_order_relaxed);

@@ -498,7 +498,7 @@ def test_column_plan_lets_the_device_decide_once_per_column_count(sri):
         ref = ref_op.apply(X)
         op = sri.SpectralApply(n, which)
         assert op.get_option(sri.OPT_PLAN_CALIBRATION) == 1
-        first = op.apply(X)                                 # measures (four executions), ends on a complete Y
+        first = op.apply(X)                                 # measures (a warm-up pair + four timed executions), ends on a complete Y
         k1 = op.last_kernel
         second = op.apply(X)
         k2 = op.last_kernel
