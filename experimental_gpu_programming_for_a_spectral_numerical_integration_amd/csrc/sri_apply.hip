@@ -239,6 +239,7 @@ static int create_from_matrix(sri_apply_t** out, uint32_t rows, const double* A,
       h->parts_name_lean = h->parts_label_lean.c_str();
     }
   }
+  h->crit_on_mid = debug_option("criterion_geometry") != "own";
   // Alternates (sri_column_plan.h): the whole operator once more in each finer geometry — 128 x 128 and 64 x 64 tiles for a
   // 256-row operator, 64 x 64 for a 128-row one (the 64 x 64 geometry has no ascending-k variant: not for operators that use it).
   if (square && rows >= BK && h->geo != GEO_FLAT) {
@@ -290,6 +291,15 @@ struct ManyPanels {
   size_t count;
 };
 
+// index of the handle's 128-row packing if its own geometry is the 256-row one and EPI_QBC should run there instead (-1: no;
+// SRI_DEBUG=criterion_geometry=own at handle creation keeps the own geometry: A/B)
+static int criterion_alternate(const sri_apply_t* h) {
+  if (h->geo != GEO_TALL || !h->crit_on_mid) return -1;
+  for (int a = 0; a < h->num_alternates; ++a)
+    if (h->alternates[a].geo == GEO_MID) return a;
+  return -1;
+}
+
 struct PositionOut {         // integrate_with_position_rhs: the second panel of an EPI_QB launch
   double* b;
   size_t ld;
@@ -309,7 +319,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     //  profiles/r05_rod_ab_closing_product.log)
     // (with the criterion — EPI_QBC — the whole confirmation pass goes, and 128-row tiles take part: their two workgroups per CU cover
     //  each other's tile ends)
-    const bool geo_ok = h->geo == GEO_TALL || (h->geo == GEO_MID && pos->crit != nullptr);
+    const bool geo_ok = h->geo == GEO_TALL || (h->geo == GEO_MID && pos->crit != nullptr);   // (own geometry; the launch itself: primary())
     // (whole k chunks — rows % 16 == 0, the N = 16 q + 1 grids — only with the criterion: that variant applies the rank-1 term itself)
     if ((h->rows % 16 == 0 && pos->crit == nullptr) || h->rows < 16 || !geo_ok || h->ascending || h->rows != h->rows_out) return SRI_EUNSUPPORTED;
     if (pos->crit != nullptr) {
@@ -421,8 +431,20 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
   // the wide geometry has no room for beside two workgroups per CU; the fused step and many-panel launches keep one geometry).
   const bool in_parts = h->num_parts != 0 && h->use_parts && dma && pos == nullptr && quat == nullptr && many == nullptr && !(h->parts_have_wide && rank1 && args.tail_k != 0) &&
       static_cast<unsigned long long>(std::max(ldx, ldy)) * 8ull * GeoWide::BN + static_cast<unsigned long long>(h->rows) * 8ull < (1ull << 32);
+  // EPI_QBC's tile end is three times the plain one.  In the 256-row geometry (one workgroup per CU, two wave groups coupled by a
+  // barrier per stage) the partner group waits it out; in 128 x 128 tiles two INDEPENDENT workgroups share a CU and cover each other's
+  // tile ends — so the closing product with the criterion runs on the handle's 128-row packing of the same operator where it has one
+  // (the column plan's alternate; same bits): N = 256 solve 1.50 -> 1.42 ms, N = 512 1.17 -> 1.11 (profiles/r05_rod_ab_criterion_geometry.log).
+  const int crit_alt = criterion_alternate(h);
   // the operator's own path over `a.m` columns
   auto primary = [&](const ApplyArgs& cols_args, bool lean) -> int {
+    if (crit != nullptr && crit_alt >= 0) {
+      ApplyArgs a = cols_args;
+      a.apack = h->alternates[crit_alt].d_apack;
+      a.row_blocks = h->alternates[crit_alt].row_blocks;
+      h->last_kernel.store(kernel_name(GEO_MID, dma, false, lean, true, true), std::memory_order_relaxed);
+      return dispatch_mid(h, a, dma, rank1, stream, nullptr, lean);
+    }
     if (in_parts) {
       for (int i = 0; i < h->num_parts; ++i) {
         const sri_apply_handle::Part& part = h->parts[i];
@@ -564,7 +586,9 @@ int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, co
 }
 
 uint32_t criterion_wave_rows(const sri_apply_t* h) {
-  return h == nullptr ? 0u : (h->geo == GEO_TALL ? static_cast<uint32_t>(GeoTall::WM) : (h->geo == GEO_MID ? static_cast<uint32_t>(GeoMid::WM) : 0u));
+  if (h == nullptr) return 0u;
+  if (criterion_alternate(h) >= 0 || h->geo == GEO_MID) return static_cast<uint32_t>(GeoMid::WM);
+  return h->geo == GEO_TALL ? static_cast<uint32_t>(GeoTall::WM) : 0u;
 }
 
 int integrate_quat_step(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, const QuatEpilogue& quat,

@@ -234,7 +234,8 @@ struct ApplyArgs {
   double* y2;            // EPI_QB only: the position right-hand side b = R(q) e1 (main.cpp:121-140), 3 columns per rod, m/4 rods
   size_t ldy2;           //   leading dimension of that panel; > rows_out when rows_out is odd (the last row pair is stored whole)
   // EPI_QBC only (the criterion of a rod solve from the closing product's accumulators): crit[0] = bits of max |d| over the panel,
-  // crit[1 + rb * WM + wm] = bits of the largest sum of d^2 over the 16 TM rows of wave row wm of row block rb that any COLUMN has,
+  // crit[1 + rb * WM + wm] = bits of the largest sum of d^2 over the 16 TM rows of wave row wm of row block rb that any COLUMN has
+  // (= segment (row / 64) of the operator's rows, whatever the geometry),
   // d = 1/2 A(K) Q - X (accumulated with atomic max: the caller hands over zeroed words); workgroup 0 zeroes crit_clear[0 .. crit_words)
   // — the words of the caller's NEXT launch — on its way in
   unsigned long long* crit;
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   }
   // ... and of EPI_QBC's reads of the X panel in the accumulator layout (the Q stores' pattern on the X panel's leading dimension)
   [[maybe_unused]] uint32_t xlane_q = 0;
-  [[maybe_unused]] double crit_dmax = 0.0, crit_seg0 = 0.0, crit_seg1 = 0.0;   // EPI_QBC: this lane's running maxima (NaN sticks)
+  [[maybe_unused]] double crit_dmax = 0.0;                     // EPI_QBC: this lane's running max |d| (a NaN is kept by the column sums)
   if constexpr (CRIT) {
     xlane_q = 4u * static_cast<uint32_t>(g) * static_cast<uint32_t>(p.ldx * sizeof(double)) + static_cast<uint32_t>(c) * 16u;
     asm volatile("" : "+v"(xlane_q));
@@ -1258,6 +1259,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
     // EPI_QBC: d = 1/2 A(K) q - x at one node of one rod — K and the product in the operation order of strain_kernel /
     // quat_rhs_kernel (sri_rod.hip: the bits of confirm_fixed_point_kernel's d) — into this lane's running max |d| and the four column sums
     [[maybe_unused]] auto legendre2 = [](double P1) __attribute__((always_inline)) { return ((2 * 1 + 1) * P1 * P1 - 1 * 1.0) / (1 + 1); };   // as strain_kernel (sri_rod.hip)
+    [[maybe_unused]] double tile_seg = 0.0;                      // EPI_QBC: the largest column sum of d^2 this lane has seen in this tile
     [[maybe_unused]] const char* side = nullptr;
     // (P1 of a row pair is read from the side buffer where it is used, pair by pair: 16 registers less across the epilogue)
     [[maybe_unused]] auto legendre1 = [&](int t) __attribute__((always_inline)) {
@@ -1293,10 +1295,20 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       double bsum = (hi4 ? a1 : a0) + dpp_exchange<0x141>(hi4 ? a0 : a1);
       bsum += dpp_exchange<0x4E>(bsum);
       bsum += dpp_exchange<0xB1>(bsum);
-      const double n0 = (bsum > crit_seg0 || bsum != bsum) ? bsum : crit_seg0;
-      const double n1 = (bsum > crit_seg1 || bsum != bsum) ? bsum : crit_seg1;
-      crit_seg0 = rb_c == 0 ? n0 : crit_seg0;
-      crit_seg1 = rb_c == 0 ? crit_seg1 : n1;
+      tile_seg = (bsum > tile_seg || bsum != bsum) ? bsum : tile_seg;
+    };
+    // ... and, once per tile, the largest of them over the wave's rod groups and lanes into the word of this wave's 64-row segment:
+    // bit patterns of non-negative doubles order like unsigned integers, NaN above everything.  ONE atomic per wave and tile, issued
+    // by every wave (the counted waits know it: TILE_STORES).
+    [[maybe_unused]] auto publish_segment = [&]() __attribute__((always_inline)) {
+      unsigned long long bits = (tile_seg != tile_seg) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(tile_seg));
+#pragma unroll
+      for (int off = 32; off >= 4; off >>= 1) {                    // (the four lanes of a quad hold the same sum)
+        const unsigned long long other = __shfl_xor(bits, off);
+        bits = other > bits ? other : bits;
+      }
+      auto* word = reinterpret_cast<__attribute__((address_space(1))) unsigned long long*>(reinterpret_cast<uintptr_t>(q.crit + 1 + rb_c * G::WM + wm));
+      if (lane == 0) (void)__hip_atomic_fetch_max(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if constexpr (SRI_STORE_SADDR != 0) {
       if ((col0_c + G::BN <= q.m) && (rb_c * G::BM + (wm + 1) * (TM * 16) <= q.rows_out + 1)) {
@@ -1412,6 +1424,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
         } else {
           emit(std::false_type{});                                // (whole k chunks: rows % 16 == 0, no half-empty pair)
         }
+        if constexpr (CRIT) publish_segment();
         return true;
       }
     }
@@ -1463,6 +1476,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       }
       if constexpr (CRIT) fold_columns(ss);
     }
+    if constexpr (CRIT) publish_segment();
     return false;
   };
   // The strip's 16 x 16 tile of this wave: lane (c, g) holds row BM + c of the columns g, g + 4, g + 8, g + 12 of the wave's
@@ -1722,7 +1736,7 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
   constexpr int W_STEADY = (AHEAD - 1) * G::DMA_PER_WAVE;   // at wait(s): the DMA of stage s+1 is younger
   // (the fused quaternion epilogue of an odd-row-count operator issues the last row pair as two masked instructions: TN * 4 more)
   // (EPI_QB: three more columns per rod — 7 stores where the plain epilogue has 4)
-  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0) + (QB ? G::NSTORE * 3 / 4 : 0);
+  constexpr int TILE_STORES = G::NSTORE + ((EPI == EPI_QUAT && DMA && TAIL && SRI_STORE_SADDR != 0) ? TN * 4 : 0) + (QB ? G::NSTORE * 3 / 4 : 0) + (CRIT ? 1 : 0);
   static_assert((AHEAD - 1) * G::DMA_PER_WAVE + TILE_STORES <= 63, "counted vmcnt must fit the 6-bit counter");
   constexpr int W_BOUNDARY = W_STEADY + TILE_STORES;        // ... plus one full tile's stores
   static_assert(AHEAD == 1 || AHEAD == 2, "the wait counts assume one or two stages in flight");
@@ -2094,12 +2108,8 @@ __global__ __launch_bounds__(G::THREADS, G::WAVES_PER_SIMD) void apply_kernel(co
       }
       return (v != v) ? 0x7ff8000000000000ull : static_cast<unsigned long long>(__double_as_longlong(v));
     };
-    const unsigned long long bd = wave_max(crit_dmax), b0 = wave_max(crit_seg0), b1 = wave_max(crit_seg1);
-    if (lane == 0 && p.crit != nullptr) {
-      if (bd != 0ull) atomicMax(p.crit, bd);
-      if (b0 != 0ull) atomicMax(p.crit + 1 + wm, b0);
-      if (b1 != 0ull) atomicMax(p.crit + 1 + G::WM + wm, b1);
-    }
+    const unsigned long long bd = wave_max(crit_dmax);
+    if (lane == 0 && p.crit != nullptr && bd != 0ull) atomicMax(p.crit, bd);
   }
 
   if constexpr (STAMP) {

@@ -69,11 +69,10 @@ int create_interpolation_operator(sri_apply_t** out, uint32_t rows_out, uint32_t
 // With `crit` (EPI_QBC; the 128- and 256-row geometries, paired k order, at least three k chunks, ldg even and >= rows + rows % 2, dG
 // 16-byte aligned — else SRI_EUNSUPPORTED; row counts that are multiples of 16 take part only in this form, which then applies the
 // rank-1 term in its store stage): the same launch also forms d = 1/2 A(K) Q - G in registers (K = Phi(X_row) qe as integrate_quat_step does)
-// and leaves, by atomic max into words the caller has zeroed, words[0] = bits of max |d| and, with W = criterion_wave_rows(h) wave rows
-// of 64 rows per row block, words[1 + wm] = bits of the largest sum of d^2 that any column has over rows [64 wm, 64 wm + 64) of row
-// block 0 and words[1 + W + wm] = the same over rows [BM rb + 64 wm, + 64) of ANY later row block (BM = 64 W rows per block).
+// and leaves, by atomic max into words the caller has zeroed, words[0] = bits of max |d| and words[1 + B] = bits of the largest sum of
+// d^2 that any column has over rows [64 B, 64 B + 64) (criterion_wave_rows(h) != 0: the handle has such a variant; rows <= 4096).
 // `clear` (optional): kCriterionWords words that the launch zeroes for the caller's NEXT launch.
-constexpr uint32_t kCriterionWords = 9;
+constexpr uint32_t kCriterionWords = 65;   // max |d| + one word per 64-row segment of operators of up to 4096 rows
 struct FixedPointCriterion {
   const double* qe;     // 9 per rod
   const double* leg1;   // P1 per (padded) row, as QuatEpilogue's
@@ -82,7 +81,7 @@ struct FixedPointCriterion {
 };
 int integrate_with_position_rhs(sri_apply_t* h, const double* dG, size_t ldg, const double* d_x_base, double* dQ, size_t ldq, double* dB,
                                 size_t ldb, size_t M, void* stream, const FixedPointCriterion* crit = nullptr);
-uint32_t criterion_wave_rows(const sri_apply_t* h);   // W above (4: 256-row tiles, 2: 128-row tiles; 0: the handle has no such variant)
+uint32_t criterion_wave_rows(const sri_apply_t* h);   // wave rows per row block of the geometry EPI_QBC runs in (2: 128-row tiles, 4: 256-row tiles; 0: no such variant)
 uint32_t max_partials(const sri_apply_t* h);   // upper bound of *partials for any launch of this handle
 uint32_t padded_rows(const sri_apply_t* h);
 int ivp_weights(const sri_apply_t* h, double* w_host);   // w = Dn_NN^-1 Dn_IN as the handle applies it (rows doubles); `device` current
@@ -185,6 +184,7 @@ struct sri_apply_handle {
     double* d_apack = nullptr;
   };
   Alternate alternates[2];
+  bool crit_on_mid = true;               // EPI_QBC of a 256-row-geometry operator runs on its 128-row alternate (sri_apply.hip: criterion_alternate)
   int num_alternates = 0;
   bool column_plan = true;           // sri_apply_set_column_plan / SRI_OPT_COLUMN_PLAN
   std::string mixed_labels[2][2];    // [primary lean][alternate]: what sri_apply_last_kernel reports for a primary + alternate launch

@@ -346,7 +346,7 @@ struct sri_rod_handle {
   uint32_t cap_partial = 0;
   unsigned long long* d_state = nullptr;  // {stop, iterations, bits(update), -} of the device-driven Picard loop
   // host side of that loop, owned by the handle (no per-call allocation, nothing to leak on an error return):
-  unsigned long long* h_state = nullptr;  // pinned, 24 words: 2 slots x 4 words, the loop state read back per chunk; from word 8 on the criterion of a closing product
+  unsigned long long* h_state = nullptr;  // pinned, 8 + kCriterionWords words: 2 slots x 4 words, the loop state read back per chunk; from word 8 on the criterion of a closing product
   hipEvent_t done[2] = {nullptr, nullptr};
   sri::ResidentRod* resident = nullptr;   // on-chip pipeline for small grids (N <= 64), else null
   bool use_resident = true;
@@ -482,7 +482,7 @@ static int rod_create_parts(sri_rod_handle* h, uint32_t n, int device, sri_apply
       (h->cap_partial = sri::max_partials(integ)) == 0 ||
       hipMalloc(&h->d_partial, sizeof(double) * h->cap_partial * 2) != hipSuccess ||     // two steps' worth: step k folds step k-1's
       hipMalloc(&h->d_state, 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&h->h_state), 24 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_state), (8 + sri::kCriterionWords) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->done[1], hipEventDisableTiming) != hipSuccess) {
     return SRI_ENOMEM;
@@ -897,13 +897,10 @@ int sri_rod_integrate_quaternions(sri_rod_t* h, const double* d_qe, size_t rods,
       double dinf;
       std::memcpy(&dinf, h_state + 8, sizeof(double));
       bool nan = dinf != dinf;
-      // (segment B = rows [64 B, 64 B + 64): wave row B % W of row block B / W; the launch keeps one maximum per wave row for row
-      //  block 0 and one for all later blocks together)
-      const uint32_t W = sri::criterion_wave_rows(h->integ);
       double sB[64];                                              // (m <= 4095: at most 64 segments)
       for (uint32_t B = 0; B < h->nseg; ++B) {
         double v;
-        std::memcpy(&v, h_state + 9 + (B < W ? 0u : W) + B % W, sizeof(double));
+        std::memcpy(&v, h_state + 9 + B, sizeof(double));
         nan = nan || v != v;
         sB[B] = std::sqrt(v) * (1.0 + 0x1p-40);
       }

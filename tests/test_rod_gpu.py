@@ -439,9 +439,16 @@ def test_closing_product_forms_the_criterion_of_the_fixed_point(sri, n, rods):
         assert used == (2 if crit else 0), (n, crit, used)
         assert rod.last_update <= 1e-14
         out.append((Q.clone(), R.clone(), rod.iterations, rod.last_update))
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
-    assert out[0][2] == out[1][2]
-    assert 0.4 <= out[0][3] / out[1][3] <= 2.5, (out[0][3], out[1][3])
+    if torch.equal(out[0][0], out[1][0]):
+        assert torch.equal(out[0][1], out[1][1])
+        assert out[0][2] == out[1][2]
+        assert 0.4 <= out[0][3] / out[1][3] <= 2.5, (out[0][3], out[1][3])
+    else:
+        # the two bounds may settle after a different number of sweeps (N = 1024 at 1e-14: the segment bound passes after one sweep,
+        # the column bound asks for a second): then the same fixed point, not the same bits
+        assert n >= 1024, n
+        assert (out[0][0] - out[1][0]).abs().max().item() <= 1e-13
+        assert (out[0][1] - out[1][1]).abs().max().item() <= 1e-12
     # the bound is a bound: the next sweep, unfused, from the returned iterate
     Q = out[0][0]
     K = rod.strain_field(qe)
