@@ -532,7 +532,14 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
     sri_apply_handle::PlanVerdict* verdict = nullptr;
     for (int i = 0; i < h->plan_verdict_count; ++i)
       if (h->plan_verdicts[i].cols == M && h->plan_verdicts[i].rank1 == rank1) verdict = &h->plan_verdicts[i];
-    if (verdict != nullptr) return execute(verdict->use_plan ? choice : own_only);
+    // (the first call of a process finds the device in its idle state, and four launches of half a millisecond on a clock that is
+    //  still settling have decided wrongly — N = 320 in two of seven sweeps on different boxes, 0.77 instead of 0.83 of the peak for
+    //  the rest of the process: the sixteenth call at the column count measures once more, and THAT verdict stays)
+    const bool recheck = verdict != nullptr && verdict->calls + 1 == sri_apply_handle::kPlanRecheckCall;
+    if (verdict != nullptr && !recheck) {
+      if (verdict->calls < sri_apply_handle::kPlanRecheckCall) ++verdict->calls;
+      return execute(verdict->use_plan ? choice : own_only);
+    }
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
       (void)hipGetLastError();
@@ -554,9 +561,12 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       SRI_HIP(hipEventSynchronize(h->plan_events[4]));
       float t[4] = {0, 0, 0, 0};
       for (int i = 0; i < 4; ++i) SRI_HIP(hipEventElapsedTime(&t[i], h->plan_events[i], h->plan_events[i + 1]));
-      sri_apply_handle::PlanVerdict& v = h->plan_verdicts[h->plan_verdict_next];
-      h->plan_verdict_next = (h->plan_verdict_next + 1) % sri_apply_handle::kPlanVerdicts;
-      if (h->plan_verdict_count < sri_apply_handle::kPlanVerdicts) ++h->plan_verdict_count;
+      sri_apply_handle::PlanVerdict& v = recheck ? *verdict : h->plan_verdicts[h->plan_verdict_next];
+      if (!recheck) {
+        h->plan_verdict_next = (h->plan_verdict_next + 1) % sri_apply_handle::kPlanVerdicts;
+        if (h->plan_verdict_count < sri_apply_handle::kPlanVerdicts) ++h->plan_verdict_count;
+      }
+      v.calls = recheck ? sri_apply_handle::kPlanRecheckCall : 1u;
       v.cols = M;
       v.rank1 = rank1;
       v.own_us = 1e3f * 0.5f * (t[0] + t[3]);
@@ -574,6 +584,7 @@ static int run(sri_apply_t* h, const double* dX, size_t ldx, double* dY, size_t 
       }
       return SRI_OK;
     }
+    if (verdict != nullptr) return execute(verdict->use_plan ? choice : own_only);   // (a capture at the re-check call: next time)
   }
   return execute(choice);
 }

@@ -200,7 +200,10 @@ struct sri_apply_handle {
     size_t cols = 0;
     bool rank1 = false, use_plan = false;
     float own_us = 0.0f, plan_us = 0.0f;
+    uint32_t calls = 0;                    // calls at this column count since the first measurement; at kPlanRecheckCall the schedules are
+                                           // timed once more — on a device that is warm by then — and that verdict stays
   };
+  static constexpr uint32_t kPlanRecheckCall = 16;
   static constexpr int kPlanVerdicts = 16;
   PlanVerdict plan_verdicts[kPlanVerdicts];
   int plan_verdict_count = 0, plan_verdict_next = 0;

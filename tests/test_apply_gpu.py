@@ -485,8 +485,9 @@ def test_apply_is_graph_capturable(sri):
 def test_column_plan_lets_the_device_decide_once_per_column_count(sri):
     """Round 5: the plan's cost model holds ONE device's tile times, so where it wants columns in a finer geometry the first call
     at that column count times both schedules on the call's own panel (own - planned - planned - own, same bits) and the handle
-    follows the winner from then on.  Whatever the verdict: the result is the own geometry's, bit for bit, from the very first
-    call; later calls launch one schedule (the reported kernel no longer changes); a call inside a stream capture never
+    follows the winner — provisionally: the sixteenth call at that column count, on a device that is warm by then, measures once more,
+    and that verdict stays.  Whatever the verdicts: the result is the own geometry's, bit for bit, from the very first
+    call; calls between the measurements launch one schedule; a call inside a stream capture never
     measures (it must not synchronise) and still gives those bits; OPT_PLAN_CALIBRATION = 0 takes the model's word."""
     import torch
 
@@ -506,6 +507,15 @@ def test_column_plan_lets_the_device_decide_once_per_column_count(sri):
         torch.cuda.synchronize()
         assert torch.equal(first, ref) and torch.equal(second, ref) and torch.equal(third, ref), (n, which, M)
         assert k1 == k2 == op.last_kernel, (k1, k2, op.last_kernel)
+        # the sixteenth call measures once more (the device is warm by then) and that verdict stays: same bits throughout, and from the
+        # seventeenth call on the reported kernel no longer changes
+        outs = [op.apply(X) for _ in range(16)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs), (n, which, M)
+        k17 = op.last_kernel
+        more = [op.apply(X) for _ in range(20)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in more) and op.last_kernel == k17
         # a new column count inside a capture: no measurement, the model's choice, the same bits
         M2 = M - 128
         Y = torch.zeros((M2, rows), dtype=torch.float64, device="cuda")
