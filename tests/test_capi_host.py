@@ -36,6 +36,28 @@ def test_library_is_gfx950_only(sri):
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
 
 
+def test_library_surface_one_environment_hook_and_no_diagnostic_scaffolding(sri):
+    """Round 4's review found eleven getenv switches and wrong-result ablation macros in the product.  What holds now: the sources
+    call getenv ONCE, for SRI_DEBUG (A/B scaffolding of tools/, read where a handle is created); the built library holds no other
+    SRI_* environment name; the kernel's STAMP / ABL parameters and SRI_TAIL_ABL are refused outside -DSRI_DIAG, which the product
+    Makefile never sets."""
+    csrc = os.path.join(os.path.dirname(sri.library_path()), "csrc")
+    calls = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            calls += [(f, m) for m in re.findall(r"getenv\s*\(\s*\"([^\"]*)\"", text)]
+            assert len(re.findall(r"\bgetenv\b", text)) == len([c for c in calls if c[0] == f]), f"{f}: a getenv without a literal name"
+    assert calls == [("sri_host.cpp", "SRI_DEBUG")], calls
+    blob = open(sri.library_path(), "rb").read()
+    assert sorted(set(re.findall(rb"SRI_[A-Z][A-Z_]{3,}(?=\0)", blob))) == [b"SRI_DEBUG"]
+    make = open(os.path.join(csrc, "Makefile")).read()
+    assert "SRI_DIAG" not in make
+    kernel = open(os.path.join(csrc, "sri_apply_kernel.h")).read()
+    assert re.search(r"#if !defined\(SRI_DIAG\)\s*\n\s*static_assert\(!STAMP && ABL == 0", kernel)
+    assert re.search(r'#error "SRI_TAIL_ABL is diagnostic scaffolding', kernel)
+
+
 @pytest.mark.parametrize("n", [2, 3, 16, 63, 64, 255, 256, 1024])
 def test_host_formers_bit_identical_to_oracle(sri, oracle, n):
     assert np.array_equal(sri.ComputeChebyshevPoints(n), oracle.points(n))
